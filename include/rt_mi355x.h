@@ -1,0 +1,232 @@
+/*
+ * rt_mi355x.h -- C ABI of the MI355X (gfx950) rendering backend.
+ *
+ * The library replaces the per-pixel hot path of the reference ray tracer:
+ * the tile/pixel/sample loop, camera-ray generation, scene traversal,
+ * Sphere/Plane/TriObj(+BVH) intersection, the path integrator with next-event
+ * estimation and MIS, the Blinn material and spherical-light samplers, and
+ * the sRGB/8-bit resolve.  Scene loading, the Node/Object/Material/Light
+ * object model and PNG output stay on the host side of this boundary.
+ *
+ * Conventions
+ *   - every entry point is extern "C", takes plain pointers and sizes, returns
+ *     an rt_status (0 = OK, negative = error) and never throws or aborts;
+ *     rt_last_error() returns the text of the last failure on a context;
+ *   - matrices are 3x4, column-major, 12 floats: cell[0..2] = first column,
+ *     cell[9..11] = translation (the reference's Matrix34f, cyMatrix.h:1089-1100);
+ *   - all arithmetic is IEEE binary32 without FMA contraction, so primary-hit
+ *     depth and object ids are bit-identical to a CPU build of the reference
+ *     made with -ffp-contract=off;
+ *   - one rt_ctx is bound to one GPU and may be used by one host thread at a time.
+ *
+ * Reference interfaces replaced (paths relative to the reference checkout):
+ *   class Renderer                      src/renderer.h:205-238
+ *   threadRenderTiles / tracePath       src/main.cpp:160-385
+ *   Renderer::TraceRay/TraceShadowRay   src/main.cpp:115-125
+ */
+#ifndef RT_MI355X_H
+#define RT_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 1
+
+typedef struct rt_ctx rt_ctx;
+
+typedef enum rt_status {
+    RT_OK = 0,
+    RT_ERR_INVALID = -1,     /* bad argument (null pointer, negative size, index out of range) */
+    RT_ERR_NO_DEVICE = -2,   /* no usable GPU / HIP runtime failed to initialise */
+    RT_ERR_HIP = -3,         /* a HIP call failed; see rt_last_error */
+    RT_ERR_UNSUPPORTED = -4, /* scene uses a feature outside the supported set */
+    RT_ERR_IO = -5,          /* file could not be read or parsed */
+    RT_ERR_STATE = -6        /* call order violated (e.g. render before scene upload) */
+} rt_status;
+
+/* ---- scene description (flattened form of the reference's object model) ---- */
+
+typedef enum rt_prim { RT_PRIM_NONE = 0, RT_PRIM_SPHERE = 1, RT_PRIM_PLANE = 2, RT_PRIM_MESH = 3 } rt_prim;
+typedef enum rt_light_type { RT_LIGHT_AMBIENT = 0, RT_LIGHT_DIRECT = 1, RT_LIGHT_POINT = 2 } rt_light_type;
+
+/* One scene-graph node (reference: class Node + Transformation, src/scene.h:155-195,414-454).
+ * Nodes are stored in depth-first pre-order; node 0 is the root; parent < index. */
+typedef struct rt_node {
+    float tm[12];     /* node-to-parent transform */
+    float itm[12];    /* its inverse */
+    int32_t parent;   /* -1 for the root */
+    int32_t prim;     /* rt_prim */
+    int32_t mesh;     /* index into rt_scene_desc.meshes when prim == RT_PRIM_MESH, else -1 */
+    int32_t material; /* index into rt_scene_desc.materials, -1 = none */
+} rt_node;
+
+/* BVH node as the reference lays it out (cyBVH.h:187-200): 6 floats of bounds
+ * (min xyz, max xyz) + one data word (bit 31 = leaf; leaf: bits 28..30 = count-1,
+ * bits 0..27 = first element; inner: index of the first child, second = first+1).
+ * Node 0 is unused, node 1 is the root. */
+typedef struct rt_bvh_node {
+    float bounds[6];
+    uint32_t data;
+} rt_bvh_node;
+
+/* Triangle mesh (reference: TriObj = cyTriMesh + BVHTriMesh, src/objects.h:50-71).
+ * All index arrays hold 3 indices per face. vn/fn and vt/ft are mandatory: the
+ * reference dereferences both for every triangle hit (src/TriObj.cpp:126-134). */
+typedef struct rt_mesh {
+    const float *v;      uint32_t nv;   /* positions,  3 floats each */
+    const float *vn;     uint32_t nvn;  /* normals,    3 floats each */
+    const float *vt;     uint32_t nvt;  /* tex coords, 3 floats each */
+    const uint32_t *f;                  /* position indices  [nf*3] */
+    const uint32_t *fn;                 /* normal indices    [nf*3] */
+    const uint32_t *ft;                 /* tex-coord indices [nf*3] */
+    uint32_t nf;
+    const rt_bvh_node *bvh_nodes; uint32_t n_bvh_nodes; /* including the unused node 0 */
+    const uint32_t *bvh_elements;       /* face ids referenced by the leaves [nf] */
+    uint32_t bvh_depth;                 /* depth of the deepest leaf, root = 0 */
+} rt_mesh;
+
+/* Blinn material constants (reference: MtlBasePhongBlinn, src/materials.h:52-60). */
+typedef struct rt_material {
+    float diffuse[3];
+    float specular[3];
+    float glossiness;
+    float emission[3];
+    float reflection[3];
+    float refraction[3];
+    float absorption[3];
+    float ior;
+} rt_material;
+
+/* Light (reference: AmbientLight/DirectLight/PointLight, src/lights.h). */
+typedef struct rt_light {
+    int32_t type; /* rt_light_type */
+    float intensity[3];
+    float position[3];
+    float direction[3];
+    float size;
+    float attenuation;
+} rt_light;
+
+typedef struct rt_scene_desc {
+    const rt_node *nodes;         uint32_t n_nodes;
+    const rt_mesh *meshes;        uint32_t n_meshes;
+    const rt_material *materials; uint32_t n_materials;
+    const rt_light *lights;       uint32_t n_lights;
+    float background[3];  /* constant background colour (src/scene.h:502) */
+    float environment[3]; /* constant environment colour (src/scene.h:503) */
+} rt_scene_desc;
+
+/* Camera as the reference holds it after Camera::Load (src/scene.h:458-480,
+ * src/xmlload.cpp:104-120): dir is normalised target-pos, up is re-orthogonalised. */
+typedef struct rt_camera {
+    float pos[3], dir[3], up[3];
+    float fov, focaldist, dof;
+    int32_t width, height;
+    int32_t srgb;
+} rt_camera;
+
+typedef enum rt_mode { RT_MODE_PATH = 0 } rt_mode;
+
+/* Everything the reference fixes at compile time (src/main.cpp:93,107,164,
+ * 220-221,262,273-274,369) plus the seeding convention and the tile shard. */
+typedef struct rt_render_params {
+    int32_t mode;          /* rt_mode */
+    int32_t min_spp;       /* reference: 128 */
+    int32_t max_spp;       /* reference: 128 */
+    float delta_max;       /* reference: 0.01 */
+    int32_t max_bounces;   /* reference: 50 */
+    float bias;            /* reference: 0.002 */
+    int32_t halton_period; /* reference: 16 (1..64) */
+    int32_t tile_size;     /* reference: 16 */
+    int32_t tile_rank;     /* render tiles t with t % tile_world == tile_rank */
+    int32_t tile_world;    /* 1 = whole image */
+    uint64_t seed;         /* frame seed; pixel p uses seed + p*0x9E3779B97F4A7C15,
+                              PCG stream 0 for the four per-pixel offsets and
+                              stream k+1 for sample k */
+} rt_render_params;
+
+/* Output planes, row-major, row 0 = top (reference: RenderImage, src/renderer.h:38-106).
+ * Any pointer may be null. Pixels outside the tile shard are left untouched.
+ * With device_memory != 0 the pointers are device addresses on the context's GPU. */
+typedef struct rt_frame_out {
+    uint8_t *rgb;          /* [H*W*3]  8-bit colour (Color24)                         */
+    float *z;              /* [H*W]    ray parameter t of the first sample's primary hit, FLT_MAX = miss */
+    int32_t *sample_count; /* [H*W]    samples taken                                   */
+    int32_t *object_id;    /* [H*W]    pre-order node index; -1 = miss; -2-l = light l */
+    float *linear;         /* [H*W*3]  mean linear radiance before sRGB/quantisation   */
+    int32_t device_memory;
+} rt_frame_out;
+
+/* Result of one closest-hit query (reference: HitInfo, src/scene.h:78-93). */
+typedef struct rt_hit {
+    float z;         /* ray parameter, FLT_MAX on a miss */
+    float p[3];      /* world-space hit point */
+    float n[3];      /* world-space shading normal (not normalised) */
+    float uvw[3];
+    int32_t node;    /* pre-order node index; -1 miss; -2-l light l */
+    int32_t front;   /* 1 = front face */
+} rt_hit;
+
+typedef struct rt_counters {
+    uint64_t closest_rays;  /* TraceRay call equivalents       */
+    uint64_t shadow_rays;   /* TraceShadowRay call equivalents */
+    uint64_t camera_paths;
+    uint64_t box_tests;     /* BVH slab tests     */
+    uint64_t tri_tests;     /* triangle tests     */
+    double kernel_ms;       /* GPU time of the last rt_render, HIP events on the render stream */
+    double trace_kernel_ms; /* of which: the path-tracing kernel(s) */
+    uint32_t trace_launches;
+} rt_counters;
+
+/* ---- context ---- */
+int rt_abi_version(void);
+int rt_init(int device, rt_ctx **out);
+void rt_shutdown(rt_ctx *ctx);
+const char *rt_last_error(const rt_ctx *ctx); /* ctx may be null: last error of a failed rt_init */
+
+/* ---- scene / camera: replaces the reference's in-memory Scene/Camera walk ---- */
+int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *scene);
+int rt_camera_set(rt_ctx *ctx, const rt_camera *cam);
+
+/* ---- frame: replaces the thread pool + threadRenderTiles (src/main.cpp:271-385,599-606) ---- */
+int rt_render(rt_ctx *ctx, const rt_render_params *params, rt_frame_out *out);
+
+/* ---- batch queries: Renderer::TraceRay / TraceShadowRay (src/main.cpp:115-125)
+ * and tracePath (src/main.cpp:160-268) for arrays of rays. rays6 = origin xyz,
+ * direction xyz (direction need not be normalised). Host pointers. ---- */
+int rt_trace(rt_ctx *ctx, const float *rays6, int n, rt_hit *out);
+int rt_trace_shadow(rt_ctx *ctx, const float *rays6, const float *t_max, int n, int32_t *occluded);
+/* path i is traced with PCG stream i+1 of the given seed */
+int rt_trace_paths(rt_ctx *ctx, const float *rays6, int n, uint64_t seed,
+                   const rt_render_params *params, float *radiance3);
+
+int rt_get_counters(rt_ctx *ctx, rt_counters *out);
+
+/* ---- host-side helpers (no GPU needed): our own readers for the reference's
+ * scene.xml schema (src/xmlload.cpp:80-270) and OBJ meshes (cyTriMesh.h:264-497),
+ * and the reference's BVH build (cyBVH.h:122-328) ---- */
+typedef struct rt_scene_host rt_scene_host; /* owns all arrays a desc points into */
+int rt_scene_load_xml(const char *path, rt_scene_host **out, char *err, size_t err_len);
+int rt_scene_from_xml_string(const char *xml, const char *base_dir, rt_scene_host **out, char *err, size_t err_len);
+const rt_scene_desc *rt_scene_host_desc(const rt_scene_host *s);
+const rt_camera *rt_scene_host_camera(const rt_scene_host *s);
+void rt_scene_host_free(rt_scene_host *s);
+/* Append an in-memory triangle mesh (positions + tex coords, one index set for
+ * both, normals computed as the reference's ComputeNormals does) to a loaded
+ * scene and bind it to the node called node_name. */
+int rt_scene_host_set_mesh(rt_scene_host *s, const char *node_name, const float *v, const float *vt,
+                           uint32_t nv, const uint32_t *f, uint32_t nf, char *err, size_t err_len);
+
+/* BVH build over nf triangles; returns arrays the caller frees with rt_free. */
+int rt_bvh_build(const float *v, uint32_t nv, const uint32_t *f, uint32_t nf, uint32_t max_leaf,
+                 rt_bvh_node **nodes, uint32_t *n_nodes, uint32_t **elements, uint32_t *depth);
+void rt_free(void *p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_MI355X_H */

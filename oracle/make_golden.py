@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the real reference (oracle/_ref/ref_harness).
+
+TEST INFRASTRUCTURE ONLY.  Runs only in the build container, where
+/root/reference exists and `make -C oracle ref` has built the harness from the
+reference's own sources.  The fixtures hold inputs (flattened scenes, rays,
+seeds, generated scene text) and the reference's outputs for them - no
+reference source text.
+
+    python oracle/make_golden.py            # regenerate everything
+"""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+from raytracer_amd import scenes  # noqa: E402
+
+HARNESS = os.path.join(HERE, "_ref", "ref_harness")
+REF_SCENE = "/root/reference/assets/scene.xml"
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def run(scene, cmd, *args, cwd=None):
+    """Run one harness command, return {name: array}."""
+    with tempfile.TemporaryDirectory() as out:
+        subprocess.run([HARNESS, scene, out, cmd] + [str(a) for a in args], check=True, cwd=cwd,
+                       stdout=subprocess.DEVNULL)
+        res = {}
+        with open(os.path.join(out, "manifest.txt")) as fp:
+            for line in fp:
+                name, dt, *shape = line.split()
+                a = np.fromfile(os.path.join(out, name + ".bin"), dtype=np.dtype(dt))
+                res[name] = a.reshape([int(s) for s in shape])
+        return res
+
+
+def save(name, **arrays):
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("%-32s %7.1f KB" % (name + ".npz", os.path.getsize(path) / 1024))
+
+
+def scene_bundle(scene, cwd=None):
+    d = run(scene, "scene", cwd=cwd)
+    return {"scene_" + k: v for k, v in d.items()}
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    if not os.path.exists(HARNESS):
+        sys.exit("build the harness first: make -C oracle ref")
+
+    save("rng", **run(REF_SCENE, "kat_rng"))
+
+    # --- scene A: the reference's shipped scene (flattened form only) -------------
+    sa = scene_bundle(REF_SCENE)
+    save("scene_a", **sa)
+    save("kat_trace_a", **sa, **run(REF_SCENE, "kat_trace", 4096, 11, 40))
+    save("kat_samplers_a", **sa, **run(REF_SCENE, "kat_samplers", 1024, 5))
+    save("kat_paths_a", **sa, **run(REF_SCENE, "kat_paths", 4096, 3, 40))
+    img = run(REF_SCENE, "render", 7, 16, 16, 0.01, 160, 90)
+    save("image_a_160x90_s16", **sa, params=np.array([7, 16, 16, 160, 90], np.int64), delta=np.float32(0.01), **img)
+    img = run(REF_SCENE, "render", 9, 4, 32, 0.05, 96, 54)
+    save("image_a_96x54_adaptive", **sa, params=np.array([9, 4, 32, 96, 54], np.int64), delta=np.float32(0.05), **img)
+
+    with tempfile.TemporaryDirectory() as tmp:
+        # --- nested transforms + depth of field: our own scene text -----------------
+        xml = scenes.nested_scene_xml(width=96, height=54)
+        p = os.path.join(tmp, "nested.xml")
+        open(p, "w").write(xml)
+        sn = scene_bundle(p)
+        save("kat_trace_nested", xml=np.frombuffer(xml.encode(), np.uint8), **sn, **run(p, "kat_trace", 2048, 21, 40))
+        img = run(p, "render", 5, 8, 8, 0.01, 96, 54)
+        save("image_nested_96x54_s8", xml=np.frombuffer(xml.encode(), np.uint8), **sn,
+             params=np.array([5, 8, 8, 96, 54], np.int64), delta=np.float32(0.01), **img)
+
+        # --- sphere grid (the sphere/plane configuration, reduced) ------------------
+        xml = scenes.spheres_scene_xml(seed=1001, grid=4, width=96, height=54)
+        p = os.path.join(tmp, "spheres.xml")
+        open(p, "w").write(xml)
+        sb = scene_bundle(p)
+        img = run(p, "render", 7, 8, 8, 0.01, 96, 54)
+        save("image_spheres_96x54_s8", xml=np.frombuffer(xml.encode(), np.uint8), **sb,
+             params=np.array([7, 8, 8, 96, 54], np.int64), delta=np.float32(0.01), **img)
+
+        # --- triangle mesh + BVH (the 1M-triangle configuration, reduced to 1024) ---
+        mesh = scenes.heightfield(nx=32, ny=16)
+        scenes.write_obj(os.path.join(tmp, "mesh_small.obj"), mesh)
+        xml = scenes.mesh_scene_xml("mesh_small.obj", width=96, height=54)
+        p = os.path.join(tmp, "mesh.xml")
+        open(p, "w").write(xml)
+        sm = scene_bundle(p, cwd=tmp)
+        save("scene_mesh", xml=np.frombuffer(xml.encode(), np.uint8), mesh_nx=np.int32(32), mesh_ny=np.int32(16), **sm)
+        small = {k: v for k, v in sm.items()}
+        save("kat_trace_mesh", **small, **run(p, "kat_trace", 4096, 31, 40, cwd=tmp))
+        img = run(p, "render", 7, 8, 8, 0.01, 96, 54, cwd=tmp)
+        save("image_mesh_96x54_s8", **small, params=np.array([7, 8, 8, 96, 54], np.int64), delta=np.float32(0.01), **img)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,70 @@
+/*
+ * rt_oracle.h -- CPU restatement of the reference renderer's per-pixel hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is the checker the GPU path is compared
+ * against; it is never linked into, loaded by or shipped with the product
+ * library.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg may use it.
+ *
+ * Pinned: every function here is checked, bit for bit, against outputs of the
+ * reference itself (oracle/_ref, built from /root/reference/src by
+ * oracle/Makefile) committed under tests/golden/ by oracle/make_golden.py.
+ *
+ * Scene, camera and render parameters use the POD structs of the public ABI
+ * header (include/rt_mi355x.h), which are the flattened form of the
+ * reference's Scene/Camera objects.
+ */
+#ifndef RT_ORACLE_H
+#define RT_ORACLE_H
+
+#include "rt_mi355x.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* PCG32 stream (reference: class RNG, src/rng.h:29-99) */
+typedef struct orc_rng { uint64_t state, inc; } orc_rng;
+void orc_rng_set_sequence(orc_rng *r, uint64_t seq, uint64_t seed); /* rng.h:39-46 */
+void orc_rng_set_sequence1(orc_rng *r, uint64_t seq);               /* rng.h:38, seed = MixBits(seq) */
+uint32_t orc_rng_u32(orc_rng *r);                                   /* rng.h:49-57 */
+float orc_rng_float(orc_rng *r);                                    /* rng.h:60-65 */
+void orc_rng_advance(orc_rng *r, int64_t delta);                    /* rng.h:68-82 */
+float orc_halton(int index, int base);                              /* rng.h:103-112 */
+
+/* camera constants main() derives before rendering (src/main.cpp:404-414):
+ * out[0..8] = cameraToWorld (column-major 3x3), out[9] = half width,
+ * out[10] = half height, out[11] = pixel size */
+void orc_camera_derive(const rt_camera *cam, float out[12]);
+
+/* Renderer::TraceRay / TraceShadowRay (src/main.cpp:16-125) */
+typedef struct orc_stats { uint64_t closest, shadow, paths, box_tests, tri_tests, node_visits; } orc_stats;
+int orc_trace(const rt_scene_desc *sc, const float ray6[6], rt_hit *hit, orc_stats *st);
+int orc_trace_shadow(const rt_scene_desc *sc, const float ray6[6], float t_max, orc_stats *st);
+
+/* samplers (src/lights.h:208-288, src/materials.h:87-303).
+ * surf = P xyz, N xyz (normalised), V xyz (normalised view vector), front flag */
+typedef struct orc_surface { float p[3], n[3], v[3]; int front; } orc_surface;
+typedef struct orc_sample { float dir[3], mult[3], prob, dist; int lobe; } orc_sample;
+int orc_light_generate(const rt_light *l, const orc_surface *s, orc_rng *rng, orc_sample *out);
+float orc_light_pdf(const rt_light *l, const float p[3], const float dir[3]);
+int orc_mtl_generate(const rt_material *m, const orc_surface *s, orc_rng *rng, orc_sample *out);
+float orc_mtl_pdf(const rt_material *m, const orc_surface *s, const float dir[3]);
+
+/* tracePath (src/main.cpp:160-268) */
+void orc_trace_path(const rt_scene_desc *sc, const float ray6[6], orc_rng *rng,
+                    const rt_render_params *prm, float radiance[3], orc_stats *st);
+
+/* threadRenderTiles (src/main.cpp:271-385) with per-pixel / per-sample seeding.
+ * n_threads <= 0 means one thread. Renders rows [y0,y1) (y1 <= 0: all rows) of
+ * the tile shard given in prm; out pointers are full-frame host planes. */
+int orc_render(const rt_scene_desc *sc, const rt_camera *cam, const rt_render_params *prm,
+               rt_frame_out *out, int n_threads, int y0, int y1, orc_stats *st);
+
+/* sRGB + 8-bit quantisation (cyColor.h:98,324-325) */
+void orc_resolve_pixel(const float linear[3], int srgb, uint8_t rgb[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,263 @@
+"""Synthetic scenes in the reference's scene.xml / OBJ formats.
+
+The reference ships a single scene (``assets/scene.xml``) and no mesh asset, so
+the benchmark scenes are generated: deterministic, parameterised only by the
+sizes below.  Vertex coordinates are quantised to 6 decimals *before* use so
+that the in-memory arrays and an OBJ text file written from them parse to the
+same binary32 values.
+"""
+import numpy as np
+
+PHASES = ((5.58423974, 6.03632667), (4.13504349, 0.95037259),
+          (4.35124413, 0.95581374), (2.04381011, 1.07836715))
+
+
+def _quant6(x):
+    """Round to 6 decimals as integers of micro-units (what '%.6f' text would hold)."""
+    return np.rint(np.asarray(x, np.float64) * 1e6).astype(np.int64)
+
+
+def _from_q(q):
+    return (q.astype(np.float64) / 1e6).astype(np.float32)
+
+
+def heightfield(nx=1000, ny=500, x_half=20.0, y_half=10.0):
+    """Height-field grid of nx*ny quads = 2*nx*ny triangles.
+
+    Returns dict(v [nv,3] f32, vt [nv,3] f32, f [nf,3] u32, qv, qvt) where qv/qvt
+    are the micro-unit integers the floats were derived from.
+    z = sum_o 1.5*2^-o * sin(2^o*0.7x+phi_o) * cos(2^o*0.9y+psi_o)
+    """
+    xs = np.linspace(-x_half, x_half, nx + 1)
+    ys = np.linspace(-y_half, y_half, ny + 1)
+    X, Y = np.meshgrid(xs, ys)  # row-major, x fastest
+    Z = np.zeros_like(X)
+    for o, (phi, psi) in enumerate(PHASES):
+        Z += 1.5 * 2.0 ** (-o) * np.sin(2.0 ** o * 0.7 * X + phi) * np.cos(2.0 ** o * 0.9 * Y + psi)
+    qv = _quant6(np.stack([X, Y, Z], -1).reshape(-1, 3))
+    qvt = _quant6(np.stack([X / (2 * x_half) + 0.5, Y / (2 * y_half) + 0.5, np.zeros_like(X)], -1).reshape(-1, 3))
+    idx = (np.arange(ny)[:, None] * (nx + 1) + np.arange(nx)[None, :]).reshape(-1).astype(np.uint32)
+    a, b, c, d = idx, idx + 1, idx + nx + 2, idx + nx + 1
+    f = np.empty((idx.size * 2, 3), np.uint32)
+    f[0::2] = np.stack([a, b, c], -1)
+    f[1::2] = np.stack([a, c, d], -1)
+    return dict(v=_from_q(qv), vt=_from_q(qvt), f=f, qv=qv, qvt=qvt)
+
+
+def _fmt6(q):
+    s = "-" if q < 0 else ""
+    q = abs(int(q))
+    return "%s%d.%06d" % (s, q // 1000000, q % 1000000)
+
+
+def write_obj(path, mesh):
+    """OBJ text with `v`, `vt` and `f a/a b/b c/c` records (no normals: the reader computes them)."""
+    with open(path, "w") as fp:
+        for r in mesh["qv"]:
+            fp.write("v %s %s %s\n" % (_fmt6(r[0]), _fmt6(r[1]), _fmt6(r[2])))
+        for r in mesh["qvt"]:
+            fp.write("vt %s %s %s\n" % (_fmt6(r[0]), _fmt6(r[1]), _fmt6(r[2])))
+        for a, b, c in mesh["f"] + 1:
+            fp.write("f %d/%d %d/%d %d/%d\n" % (a, a, b, b, c, c))
+
+
+def mesh_scene_xml(obj_name="mesh_1m.obj", width=1920, height=1080):
+    """1M-triangle configuration: mesh + glass sphere + mirror sphere + floor, one spherical light."""
+    return f"""<xml>
+  <scene>
+    <object type="obj" name="{obj_name}" material="smooth"/>
+    <object type="sphere" name="glass" material="glass">
+      <scale value="3"/>
+      <translate x="6" y="-2" z="6"/>
+    </object>
+    <object type="sphere" name="mirror" material="mirror">
+      <scale value="3"/>
+      <translate x="-6" y="2" z="6"/>
+    </object>
+    <object type="plane" name="floor" material="floor">
+      <scale value="60"/>
+      <translate z="-4"/>
+    </object>
+    <material type="blinn" name="smooth">
+      <diffuse value="0.7"/>
+      <specular value="0.3"/>
+      <glossiness value="64"/>
+    </material>
+    <material type="blinn" name="glass">
+      <diffuse value="0"/>
+      <specular value="0"/>
+      <glossiness value="1024"/>
+      <refraction value="0.9" index="1.52"/>
+    </material>
+    <material type="blinn" name="mirror">
+      <diffuse value="0"/>
+      <specular value="0.9"/>
+      <glossiness value="128"/>
+    </material>
+    <material type="blinn" name="floor">
+      <diffuse value="0.7"/>
+      <specular value="0"/>
+    </material>
+    <light type="point" name="pointLight">
+      <intensity value="2500"/>
+      <position x="0" y="0" z="30"/>
+      <size value="1"/>
+    </light>
+  </scene>
+  <camera gamma="sRGB">
+    <position x="0" y="-45" z="22"/>
+    <target x="0" y="0" z="0"/>
+    <up x="0" y="0" z="1"/>
+    <fov value="40"/>
+    <width value="{width}"/>
+    <height value="{height}"/>
+  </camera>
+</xml>
+"""
+
+
+class _PCG32:
+    """PCG32 with the reference's one-argument seeding (src/rng.h:34,38,90-98); scene generation only."""
+    M = 0x5851F42D4C957F2D
+    MASK = (1 << 64) - 1
+
+    def __init__(self, seq):
+        v = seq
+        v ^= v >> 31; v = (v * 0x7FB5D329728EA185) & self.MASK
+        v ^= v >> 27; v = (v * 0x81DADEF4BC2DD44D) & self.MASK
+        v ^= v >> 33
+        self.state, self.inc = 0, ((seq << 1) | 1) & self.MASK
+        self.u32(); self.state = (self.state + v) & self.MASK; self.u32()
+
+    def u32(self):
+        old = self.state
+        self.state = (old * self.M + self.inc) & self.MASK
+        xs = (((old >> 18) ^ old) >> 27) & 0xFFFFFFFF
+        rot = old >> 59
+        return ((xs >> rot) | (xs << ((-rot) & 31))) & 0xFFFFFFFF
+
+    def f32(self):
+        r = np.float32(self.u32()) * np.float32(2.0 ** -32)
+        return float(min(r, np.float32(1.0 - 2.0 ** -24)))
+
+
+_PRESETS = (
+    dict(kd=(.7, .7, .7), ks=0.0, g=20),
+    dict(kd=(.7, .14, .14), ks=0.0, g=20),
+    dict(kd=(.14, .7, .14), ks=0.0, g=20),
+    dict(kd=(.7, .7, .7), ks=0.3, g=64),
+    dict(kd=(.5, .5, .5), ks=0.3, g=20),
+    dict(kd=(0, 0, 0), ks=0.9, g=128, kr=0.9),
+    dict(kd=(0, 0, 0), ks=0.0, g=1024, kt=0.9, ior=1.52),
+    dict(kd=(.35, .35, .35), ks=0.6, g=128),
+)
+
+
+def spheres_scene_xml(seed=1001, grid=8, width=1920, height=1080):
+    """Sphere/plane-only configuration: grid*grid spheres over a floor and a back wall."""
+    rng = _PCG32(seed)
+    out = ["<xml>", "  <scene>",
+           '    <object type="plane" name="floor" material="wall"><scale value="40"/></object>',
+           '    <object type="plane" name="back" material="wall"><scale value="40"/>'
+           '<rotate angle="90" x="1"/><translate y="20"/></object>']
+    half = (grid - 1) / 2.0
+    for iy in range(grid):
+        for ix in range(grid):
+            r = 0.8 + 0.8 * rng.f32()
+            m = int(8 * rng.f32())
+            out.append(f'    <object type="sphere" name="s{iy}_{ix}" material="m{m}"><scale value="{r:.9g}"/>'
+                       f'<translate x="{(ix - half) * 4.5:.9g}" y="{(iy - half) * 4.5:.9g}" z="{r:.9g}"/></object>')
+    out.append('    <material type="blinn" name="wall"><diffuse value="0.7"/><specular value="0"/></material>')
+    for i, p in enumerate(_PRESETS):
+        kd = p["kd"]
+        s = [f'    <material type="blinn" name="m{i}">',
+             f'<diffuse r="{kd[0]:.9g}" g="{kd[1]:.9g}" b="{kd[2]:.9g}"/>',
+             f'<specular value="{p["ks"]:.9g}"/><glossiness value="{p["g"]}"/>']
+        if "kr" in p:
+            s.append(f'<reflection value="{p["kr"]:.9g}"/>')
+        if "kt" in p:
+            s.append(f'<refraction value="{p["kt"]:.9g}" index="{p["ior"]:.9g}"/>')
+        s.append("</material>")
+        out.append("".join(s))
+    out += ['    <light type="point" name="pointLight"><intensity value="1500"/>'
+            '<position x="0" y="0" z="30"/><size value="1"/></light>',
+            "  </scene>",
+            '  <camera gamma="sRGB">', '    <position x="0" y="-45" z="18"/>', '    <target x="0" y="0" z="2"/>',
+            '    <up x="0" y="0" z="1"/>', '    <fov value="40"/>',
+            f'    <width value="{width}"/>', f'    <height value="{height}"/>', "  </camera>", "</xml>", ""]
+    return "\n".join(out)
+
+
+def nested_scene_xml(width=320, height=180):
+    """Small closed room built from a two-level node hierarchy with rotations,
+    non-uniform scales and a thin-lens camera; exercises every transform path."""
+    return f"""<xml>
+  <scene>
+    <object name="room">
+      <rotate angle="12" z="1"/>
+      <translate x="1" y="2" z="10"/>
+      <object type="plane" name="floor" material="white">
+        <scale x="18" y="22" z="1"/>
+        <translate z="-10"/>
+      </object>
+      <object type="plane" name="ceil" material="white">
+        <scale value="22"/>
+        <rotate angle="180" y="1"/>
+        <translate z="10"/>
+      </object>
+      <object type="plane" name="back" material="blue">
+        <scale value="22"/>
+        <rotate angle="90" x="1"/>
+        <translate y="16"/>
+      </object>
+      <object type="plane" name="left" material="red">
+        <scale value="22"/>
+        <rotate angle="90" y="1"/>
+        <translate x="-13"/>
+      </object>
+      <object type="plane" name="right" material="white">
+        <scale value="22"/>
+        <rotate angle="-90" y="1"/>
+        <translate x="13"/>
+      </object>
+      <object name="group">
+        <scale x="1.5" y="1" z="0.75"/>
+        <rotate angle="30" x="1" y="1" z="0.5"/>
+        <translate x="-2" y="1" z="-4"/>
+        <object type="sphere" name="ellipsoid" material="glossy">
+          <scale value="3"/>
+        </object>
+        <object type="sphere" name="moon" material="glass">
+          <scale value="1.25"/>
+          <translate x="4" y="-3" z="2"/>
+        </object>
+      </object>
+    </object>
+    <object type="sphere" name="mirror" material="mirror">
+      <scale value="3.5"/>
+      <translate x="6" y="4" z="4"/>
+    </object>
+    <material type="blinn" name="white"><diffuse value="0.75"/><specular value="0"/></material>
+    <material type="blinn" name="red"><diffuse r="0.8" g="0.15" b="0.1"/><specular value="0"/></material>
+    <material type="blinn" name="blue"><diffuse r="0.15" g="0.2" b="0.8"/><specular value="0.1"/><glossiness value="30"/></material>
+    <material type="blinn" name="glossy"><diffuse r="0.5" g="0.4" b="0.1"/><specular value="0.4"/><glossiness value="48"/></material>
+    <material type="blinn" name="glass"><diffuse value="0"/><specular value="0.05"/><glossiness value="512"/><refraction value="0.9" index="1.45"/></material>
+    <material type="blinn" name="mirror"><diffuse value="0"/><specular value="0.9"/><glossiness value="200"/></material>
+    <light type="point" name="lamp">
+      <intensity r="420" g="400" b="380"/>
+      <position x="1" y="1" z="17"/>
+      <size value="1.25"/>
+    </light>
+  </scene>
+  <camera gamma="sRGB">
+    <position x="2" y="-50" z="11"/>
+    <target x="0" y="0" z="9"/>
+    <up x="0" y="0" z="1"/>
+    <fov value="32"/>
+    <focaldist value="48"/>
+    <dof value="0.6"/>
+    <width value="{width}"/>
+    <height value="{height}"/>
+  </camera>
+</xml>
+"""

@@ -1,0 +1,148 @@
+"""Pin the CPU oracle against outputs of the reference itself.
+
+Every fixture under tests/golden/ was produced by oracle/_ref/ref_harness, i.e.
+by the reference's own code compiled from /root/reference/src with
+-ffp-contract=off (oracle/make_golden.py).  The oracle must reproduce them bit
+for bit: integer streams, hit records, sampler outputs, per-path radiance and
+whole seeded images.  CPU only.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oraclelib as O
+from raytracer_amd import abi
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def assert_bits_equal(a, b, what):
+    a, b = bits(a), bits(b)
+    bad = np.argwhere(a != b)
+    assert len(bad) == 0, f"{what}: {len(bad)} of {a.size} values differ, first at {bad[0]}"
+
+
+def test_rng_streams():
+    g = O.load_golden("rng")
+    L = O.lib()
+    seqs = [(0, 0), (1, 42), (921599, 0x9E3779B97F4A7C15), (0xFFFFFFFFFF, 7)]
+    r = O.Rng()
+    for i, (seq, seed) in enumerate(seqs):
+        L.orc_rng_set_sequence(C.byref(r), seq, seed)
+        u = [L.orc_rng_u32(C.byref(r)) for _ in range(64)]
+        assert np.array_equal(np.array(u, np.uint32), g["rng_u32"][i])
+        L.orc_rng_set_sequence(C.byref(r), seq, seed)
+        f = np.array([L.orc_rng_float(C.byref(r)) for _ in range(64)], np.float32)
+        assert_bits_equal(f, g["rng_f32"][i], "RandomFloat")
+    for i, s in enumerate([0, 1, 1001, 2002, 123456789012]):
+        L.orc_rng_set_sequence1(C.byref(r), s)
+        assert [L.orc_rng_u32(C.byref(r)) for _ in range(8)] == list(g["rng_onearg"][i])
+    for i, d in enumerate([1, 5, 1000, 123456789]):
+        L.orc_rng_set_sequence(C.byref(r), 3, 9)
+        L.orc_rng_advance(C.byref(r), d)
+        assert [L.orc_rng_u32(C.byref(r)) for _ in range(4)] == list(g["rng_advance"][i])
+
+
+def test_halton_tables():
+    g = O.load_golden("rng")
+    L = O.lib()
+    for b, base in enumerate([2, 3, 5, 7]):
+        h = np.array([L.orc_halton(i, base) for i in range(16)], np.float32)
+        assert_bits_equal(h, g["halton"][b], f"Halton base {base}")
+
+
+@pytest.mark.parametrize("name", ["scene_a", "image_nested_96x54_s8", "scene_mesh"])
+def test_camera_constants(name):
+    g = O.load_golden(name)
+    s = O.scene_from_golden(g)
+    out = np.zeros(12, np.float32)
+    O.lib().orc_camera_derive(C.byref(s.camera), out.ctypes.data_as(abi.f32p))
+    assert_bits_equal(out, g["scene_camera_derived"], "camera constants")
+
+
+@pytest.mark.parametrize("name", ["kat_trace_a", "kat_trace_nested", "kat_trace_mesh"])
+def test_trace_ray_kat(name):
+    g = O.load_golden(name)
+    s = O.scene_from_golden(g)
+    hits = O.trace(s, g["kat_rays"])
+    ref_hit = g["kat_flags"][:, 0].astype(bool)
+    assert np.array_equal(hits["node"], g["kat_id"]), "hit node ids"
+    assert ref_hit.sum() > len(ref_hit) // 4
+    assert_bits_equal(hits["z"], g["kat_hit"][:, 0], "z")
+    on_obj = ref_hit & (g["kat_id"] >= 0)  # light hits leave p/N in light-local units, unused downstream
+    assert np.array_equal(hits["front"][ref_hit], g["kat_flags"][ref_hit, 1])
+    assert_bits_equal(hits["p"][on_obj], g["kat_hit"][on_obj, 1:4], "p")
+    assert_bits_equal(hits["n"][on_obj], g["kat_hit"][on_obj, 4:7], "N")
+    assert_bits_equal(hits["uvw"][on_obj], g["kat_hit"][on_obj, 7:10], "uvw")
+    occ = O.trace_shadow(s, g["kat_rays"], g["kat_tmax"])
+    assert np.array_equal(occ, g["kat_flags"][:, 2]), "shadow rays"
+
+
+def test_sampler_kat():
+    g = O.load_golden("kat_samplers_a")
+    s = O.scene_from_golden(g)
+    L = O.lib()
+    n = len(g["smp_in"])
+    nm = s.desc.n_materials
+    seed = 5
+    rng = O.Rng()
+    for i in range(n):
+        inp = g["smp_in"][i]
+        P, N, rd, q = inp[0:3], inp[3:6], inp[6:9], inp[9:12]
+        N32 = (N / np.sqrt((N * N).astype(np.float32).sum(dtype=np.float32), dtype=np.float32)).astype(np.float32)
+        # normalise exactly as cyVector does: component / sqrt((x*x+y*y)+z*z)
+        ln = np.float32(np.sqrt(np.float32(np.float32(N[0] * N[0] + N[1] * N[1]) + N[2] * N[2])))
+        N32 = (N / ln).astype(np.float32)
+        ld = np.float32(np.sqrt(np.float32(np.float32(rd[0] * rd[0] + rd[1] * rd[1]) + rd[2] * rd[2])))
+        V = (-(rd / ld)).astype(np.float32)
+        surf = O.Surface()
+        surf.p[:] = [float(x) for x in P]; surf.n[:] = [float(x) for x in N32]; surf.v[:] = [float(x) for x in V]
+        surf.front = int(g["smp_front"][i])
+        smp = O.Sample()
+        L.orc_rng_set_sequence(C.byref(rng), i + 1, seed)
+        ok = L.orc_light_generate(s.desc.lights, C.byref(surf), C.byref(rng), C.byref(smp))
+        got = np.array(list(smp.dir) + list(smp.mult) + [smp.prob, smp.dist, ok], np.float32)
+        assert_bits_equal(got, g["smp_light_gen"][i], f"light GenerateSample {i}")
+        qd = np.ascontiguousarray(q, np.float32)
+        lp = L.orc_light_pdf(s.desc.lights, surf.p, qd.ctypes.data_as(abi.f32p))
+        assert_bits_equal(np.float32(lp), g["smp_light_pdf"][i], f"light GetSampleInfo {i}")
+        for m in range(nm):
+            L.orc_rng_set_sequence(C.byref(rng), i + 1, seed ^ (0x1000 + m))
+            ok = L.orc_mtl_generate(C.byref(s.desc.materials[m]), C.byref(surf), C.byref(rng), C.byref(smp))
+            fl = g["smp_mtl_flags"][i, m]
+            assert ok == fl[0], (i, m)
+            assert L.orc_rng_u32(C.byref(rng)) == np.uint32(fl[2]), f"draw count {i},{m}"
+            if ok:
+                assert smp.lobe == fl[1]
+                got = np.array(list(smp.dir) + list(smp.mult) + [smp.prob], np.float32)
+                assert_bits_equal(got, g["smp_mtl_gen"][i, m, :7], f"material GenerateSample {i},{m}")
+            mp = L.orc_mtl_pdf(C.byref(s.desc.materials[m]), C.byref(surf), qd.ctypes.data_as(abi.f32p))
+            assert_bits_equal(np.float32(mp), g["smp_mtl_pdf"][i, m], f"material GetSampleInfo {i},{m}")
+
+
+def test_path_radiance_kat():
+    g = O.load_golden("kat_paths_a")
+    s = O.scene_from_golden(g)
+    rad = O.trace_paths(s, g["path_rays"], 3, abi.default_params())
+    assert (g["path_radiance"].sum(axis=1) > 0).mean() > 0.5
+    assert_bits_equal(rad, g["path_radiance"], "tracePath radiance")
+
+
+@pytest.mark.parametrize("name", ["image_a_160x90_s16", "image_a_96x54_adaptive", "image_nested_96x54_s8",
+                                  "image_spheres_96x54_s8", "image_mesh_96x54_s8"])
+def test_seeded_images(name):
+    g = O.load_golden(name)
+    s = O.scene_from_golden(g)
+    seed, mn, mx, w, h = [int(x) for x in g["params"]]
+    prm = abi.default_params(seed=seed, min_spp=mn, max_spp=mx, delta_max=float(g["delta"]))
+    fr = O.render(s, prm, w, h)
+    assert np.array_equal(fr.object_id, g["object_id"]), "primary-hit ids"
+    assert_bits_equal(fr.z, g["z"], "z-buffer")
+    assert np.array_equal(fr.sample_count, g["sample_count"]), "sample counts"
+    assert_bits_equal(fr.linear, g["linear"], "linear radiance")
+    assert np.array_equal(fr.rgb, g["rgb"]), "8-bit image"
+    if "adaptive" in name:
+        assert len(np.unique(g["sample_count"])) > 3
