@@ -205,6 +205,9 @@ int rt_trace_paths(rt_ctx *ctx, const float *rays6, int n, uint64_t seed,
                    const rt_render_params *params, float *radiance3);
 
 int rt_get_counters(rt_ctx *ctx, rt_counters *out);
+/* box_tests / tri_tests are only counted while counting is on (a separately
+ * compiled kernel variant; the default variant carries no per-test counters) */
+int rt_set_counting(rt_ctx *ctx, int on);
 
 /* ---- host-side helpers (no GPU needed): our own readers for the reference's
  * scene.xml schema (src/xmlload.cpp:80-270) and OBJ meshes (cyTriMesh.h:264-497),

@@ -1,0 +1,252 @@
+// gfx950 kernels of the rendering hot path.
+//
+//   k_paths    one lane = one (pixel, sample) camera path: seeds its PCG stream,
+//              builds the camera ray (src/main.cpp:294-323) and runs the path
+//              integrator; writes the sample's radiance to the sample buffer
+//   k_resolve  one lane = one pixel: in-order running sums over the new samples,
+//              the variance stop test (src/main.cpp:357-372), and for finished
+//              pixels the mean, sRGB and 8-bit quantisation (src/main.cpp:375-380)
+//   k_trace*   batch forms of TraceRay / TraceShadowRay / tracePath for arrays of rays
+#pragma once
+#include "shade.h"
+#include <limits.h>
+
+namespace rtd {
+
+constexpr int kBlock = 256;
+
+struct FramePlanes {
+    uint8_t *rgb;
+    float *z;
+    int32_t *sample_count;
+    int32_t *object_id;
+    float *linear;
+};
+
+// per-pixel running state between sampling rounds
+struct PixelState {
+    float sum[3];
+    float sum_sq[3];
+    int32_t n;
+    int32_t pad;
+};
+
+RT_DEV LaneStack lane_stack(uint32_t *lds, int levels)
+{
+    LaneStack st;
+    st.id = lds + threadIdx.x;
+    st.t = reinterpret_cast<float *>(lds + levels * kBlock) + threadIdx.x;
+    st.stride = kBlock;
+    return st;
+}
+
+RT_DEV uint64_t wave_sum(uint64_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down((unsigned long long)v, o, 64);
+    return v;
+}
+
+template <bool COUNT>
+RT_DEV void flush_counters(DCounters *ctr, const PathTally &pt, const Tally<COUNT> &tl, uint32_t paths)
+{
+    const uint64_t c = wave_sum(pt.closest), s = wave_sum(pt.shadow), p = wave_sum(paths);
+    uint64_t b = 0, t = 0;
+    if (COUNT) { b = wave_sum(tl.box); t = wave_sum(tl.tri); }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&ctr->closest, (unsigned long long)c);
+        atomicAdd(&ctr->shadow, (unsigned long long)s);
+        atomicAdd(&ctr->paths, (unsigned long long)p);
+        if (COUNT) { atomicAdd(&ctr->box_tests, (unsigned long long)b); atomicAdd(&ctr->tri_tests, (unsigned long long)t); }
+    }
+}
+
+RT_DEV uint64_t pixel_seed(uint64_t frame, uint64_t pix) { return frame + pix * 0x9E3779B97F4A7C15ULL; }
+
+// fmod(a + b, 1) for a, b in [0,1): exact in binary32
+RT_DEV float frac_sum(float a, float b)
+{
+    const float s = a + b;
+    return s >= 1.0f ? s - 1.0f : s;
+}
+
+// camera ray of sample k of pixel (i, j) (src/main.cpp:303-323)
+RT_DEV Ray camera_ray(const DFrame &F, const float *halton, int i, int j, int k, const float off[4])
+{
+    const int hk = k % F.halton_period;
+    const float jx = frac_sum(halton[hk], off[0]);
+    const float jy = frac_sum(halton[64 + hk], off[1]);
+    const float px = (float)i + jx;
+    const float py = (float)j + jy;
+    const float sx = -F.half_w + F.pixel_size * px;
+    const float sy = F.half_h - F.pixel_size * py;
+    const V3 cpos = ld3(F.cam_pos);
+    const V3 dest = cpos + m3_mul(F.cam2world, mk(sx, sy, -F.focaldist));
+    const float jt = frac_sum(halton[128 + hk], off[2]);
+    const float jr = frac_sum(halton[192 + hk], off[3]);
+    const float theta = (float)((double)(jt * 2.0f) * M_PI); // float*float, then *double (main.cpp:313)
+    const float radius = __fsqrt_rn(jr);
+    const V3 lens = mk(radius * F.dof * cosf(theta), radius * F.dof * sinf(theta), 0.0f);
+    Ray r;
+    r.p = cpos + m3_mul(F.cam2world, lens);
+    r.d = dest - r.p;
+    return r;
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_paths(DScene S, DFrame F, const float *__restrict__ halton,
+                                                  const int32_t *__restrict__ active, uint64_t n_items, int k0, int nk,
+                                                  float4 *__restrict__ sbuf, FramePlanes out, DCounters *ctr)
+{
+    extern __shared__ uint32_t lds[];
+    const LaneStack st = lane_stack(lds, S.stack_levels);
+    const uint64_t item = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    PathTally pt;
+    Tally<COUNT> tl;
+    uint32_t paths = 0;
+    if (item < n_items) {
+        const uint32_t a = (uint32_t)(item / (uint32_t)nk);
+        const int kk = (int)(item - (uint64_t)a * (uint32_t)nk);
+        const int k = k0 + kk;
+        const int pix = active[a];
+        const int i = pix % F.width, j = pix / F.width;
+        const uint64_t ps = pixel_seed(F.seed, (uint64_t)pix);
+        Rng rng;
+        rng_set_sequence(rng, 0, ps);
+        float off[4];
+        off[0] = rng_float(rng); off[1] = rng_float(rng); off[2] = rng_float(rng); off[3] = rng_float(rng);
+        rng_set_sequence(rng, (uint64_t)k + 1, ps);
+        const Ray ray = camera_ray(F, halton, i, j, k, off);
+        float fz; int fid;
+        const V3 c = trace_path<COUNT>(S, F, ray, rng, st, pt, tl, &fz, &fid);
+        if (k == 0) {
+            if (out.z) out.z[pix] = fz;
+            if (out.object_id) out.object_id[pix] = fid;
+        }
+        sbuf[item] = make_float4(c.x, c.y, c.z, 0.0f);
+        paths = 1;
+    }
+    flush_counters<COUNT>(ctr, pt, tl, paths);
+}
+
+// int(float) as x86 cvttss2si does it: NaN and out-of-range give INT_MIN
+RT_DEV int x86_f2i(float f)
+{
+    if (!(f > -2147483904.0f && f < 2147483648.0f)) return INT_MIN;
+    return (int)f;
+}
+RT_DEV uint8_t to_byte(float r) // cyColor.h:324-325
+{
+    const int v = x86_f2i(r * 255 + 0.5f);
+    return v < 0 ? 0 : (v > 255 ? 255 : (uint8_t)v);
+}
+RT_DEV float lin2srgb(float cl) // cyColor.h:98
+{
+    return cl < 0.0031308f ? cl * 12.92f : powf(cl, 0.41666f) * 1.055f - 0.055f;
+}
+
+__global__ __launch_bounds__(kBlock) void k_resolve(DFrame F, const int32_t *__restrict__ active, uint32_t n_active,
+                                                    int k0, int nk, const float4 *__restrict__ sbuf,
+                                                    PixelState *__restrict__ state, FramePlanes out,
+                                                    int32_t *__restrict__ next_active, uint32_t *next_count)
+{
+    const uint32_t a = blockIdx.x * kBlock + threadIdx.x;
+    if (a >= n_active) return;
+    const int pix = active[a];
+    PixelState s;
+    if (k0 == 0) { s.sum[0] = s.sum[1] = s.sum[2] = 0.0f; s.sum_sq[0] = s.sum_sq[1] = s.sum_sq[2] = 0.0f; s.n = 0; s.pad = 0; }
+    else s = state[pix];
+    bool done = false;
+    for (int kk = 0; kk < nk && !done; ++kk) {
+        const float4 c = sbuf[(uint64_t)a * (uint32_t)nk + kk];
+        ++s.n;
+        s.sum[0] += c.x; s.sum[1] += c.y; s.sum[2] += c.z;
+        s.sum_sq[0] += c.x * c.x; s.sum_sq[1] += c.y * c.y; s.sum_sq[2] += c.z * c.z;
+        if (s.n < F.min_spp) continue;
+        // src/main.cpp:360-372
+        bool below = true;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            float sigma = (s.sum_sq[ch] - ((s.sum[ch] * s.sum[ch]) / (float)s.n)) / (float)(s.n - 1);
+            sigma = __fsqrt_rn(fmaxf(0.0f, sigma));
+            const float delta = 3.0f * (sigma / __fsqrt_rn((float)s.n));
+            below = below && (delta < F.delta_max);
+        }
+        if (below) done = true;
+    }
+    if (s.n >= F.max_spp) done = true;
+    if (!done) {
+        state[pix] = s;
+        next_active[atomicAdd(next_count, 1u)] = pix;
+        return;
+    }
+    float lin[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) lin[ch] = s.sum[ch] / (float)s.n;
+    if (out.linear) { out.linear[pix * 3] = lin[0]; out.linear[pix * 3 + 1] = lin[1]; out.linear[pix * 3 + 2] = lin[2]; }
+    if (out.rgb) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) out.rgb[pix * 3 + ch] = to_byte(F.srgb ? lin2srgb(lin[ch]) : lin[ch]);
+    }
+    if (out.sample_count) out.sample_count[pix] = s.n;
+}
+
+// ---- batch queries ----
+__global__ __launch_bounds__(kBlock) void k_trace(DScene S, const float *__restrict__ rays6, int n, rt_hit *__restrict__ out)
+{
+    extern __shared__ uint32_t lds[];
+    const LaneStack st = lane_stack(lds, S.stack_levels);
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    Ray r;
+    r.p = ld3(rays6 + (size_t)i * 6); r.d = ld3(rays6 + (size_t)i * 6 + 3);
+    Hit h;
+    Tally<false> tl;
+    const bool hit = trace_closest<false>(S, r, st, h, tl);
+    if (hit && h.node >= 0) finish_hit(S, r, h, true);
+    else { h.p = mk(0, 0, 0); h.n = mk(0, 0, 0); h.uvw = mk(0.5f, 0.5f, 0.5f); }
+    rt_hit o;
+    o.z = h.z;
+    o.p[0] = h.p.x; o.p[1] = h.p.y; o.p[2] = h.p.z;
+    o.n[0] = h.n.x; o.n[1] = h.n.y; o.n[2] = h.n.z;
+    o.uvw[0] = h.uvw.x; o.uvw[1] = h.uvw.y; o.uvw[2] = h.uvw.z;
+    o.node = hit ? h.node : -1;
+    o.front = h.front;
+    out[i] = o;
+}
+
+__global__ __launch_bounds__(kBlock) void k_trace_shadow(DScene S, const float *__restrict__ rays6,
+                                                         const float *__restrict__ t_max, int n, int32_t *__restrict__ out)
+{
+    extern __shared__ uint32_t lds[];
+    const LaneStack st = lane_stack(lds, S.stack_levels);
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    Ray r;
+    r.p = ld3(rays6 + (size_t)i * 6); r.d = ld3(rays6 + (size_t)i * 6 + 3);
+    Tally<false> tl;
+    out[i] = trace_shadow<false>(S, r, t_max[i], st, tl) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(kBlock) void k_trace_paths(DScene S, DFrame F, const float *__restrict__ rays6, int n,
+                                                        float *__restrict__ radiance3, DCounters *ctr)
+{
+    extern __shared__ uint32_t lds[];
+    const LaneStack st = lane_stack(lds, S.stack_levels);
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    PathTally pt;
+    Tally<false> tl;
+    uint32_t paths = 0;
+    if (i < n) {
+        Ray r;
+        r.p = ld3(rays6 + (size_t)i * 6); r.d = ld3(rays6 + (size_t)i * 6 + 3);
+        Rng rng;
+        rng_set_sequence(rng, (uint64_t)i + 1, F.seed);
+        const V3 c = trace_path<false>(S, F, r, rng, st, pt, tl, nullptr, nullptr);
+        radiance3[(size_t)i * 3] = c.x; radiance3[(size_t)i * 3 + 1] = c.y; radiance3[(size_t)i * 3 + 2] = c.z;
+        paths = 1;
+    }
+    flush_counters<false>(ctr, pt, tl, paths);
+}
+
+} // namespace rtd

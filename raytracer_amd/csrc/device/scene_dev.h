@@ -1,0 +1,74 @@
+// Device-resident form of a scene.  Built once per rt_scene_upload; everything a
+// ray needs is reachable from one DScene passed to the kernels by value.
+#pragma once
+#include "rt_mi355x.h"
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rtd {
+
+constexpr int kMaxSceneDepth = 6; // levels of the node hierarchy below and including the root
+
+// Scene-graph node, depth-first order.  Read with wave-uniform indices, so the
+// loads are scalar.
+struct DNode {
+    float itm[12];
+    float tm[12];
+    int32_t parent;
+    int32_t prim;
+    int32_t mesh;
+    int32_t material;
+    int32_t depth;        // root = 0
+    int32_t has_children;
+    int32_t chain[kMaxSceneDepth]; // ancestors root-first, chain[depth] = this node
+    int32_t pad[4];
+}; // 160 bytes
+
+// One triangle mesh.
+//   bvh  : 32-byte nodes, two float4 each: (min.xyz, max.x) (max.y, max.z, data, 0);
+//          the two children of a node are adjacent, the pair starts on a 64-byte line
+//   tris : 48-byte records in BVH-leaf order (indexed by element slot, not face id):
+//          (v0.xyz, v1.x) (v1.yz, v2.xy) (v2.z, face id, 0, 0) - the three position
+//          reads and the two index reads of the reference collapse into one dependent fetch
+struct DMesh {
+    const float4 *bvh;
+    const float4 *tris;
+    const uint32_t *fn; // normal indices per face
+    const uint32_t *ft; // tex-coord indices per face
+    const float *vn;
+    const float *vt;
+    uint32_t n_nodes;
+    uint32_t depth;
+};
+
+struct DScene {
+    const DNode *nodes;
+    const DMesh *meshes;
+    const rt_material *materials;
+    const rt_light *lights;
+    int32_t n_nodes;
+    int32_t n_lights;
+    float background[3];
+    int32_t stack_levels; // BVH stack entries a lane may need (deepest mesh + 2), 0 without meshes
+};
+
+// Frame constants (camera + sampling), by value in the kernel arguments.
+struct DFrame {
+    float cam_pos[3];
+    float cam2world[9];
+    float half_w, half_h, pixel_size, focaldist, dof;
+    int32_t width, height, srgb;
+    int32_t min_spp, max_spp;
+    float delta_max;
+    int32_t max_bounces;
+    float bias;
+    int32_t halton_period;
+    uint64_t seed;
+    float halton[4][64];
+};
+
+struct DCounters {
+    unsigned long long closest, shadow, paths, box_tests, tri_tests;
+};
+
+} // namespace rtd

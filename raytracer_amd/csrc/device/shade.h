@@ -1,0 +1,266 @@
+// Light and material samplers and the path integrator: the device form of
+// PointLight::GenerateSample/GetSampleInfo (src/lights.h:208-288),
+// MtlBlinn::GenerateSample/GetSampleInfo (src/materials.h:87-303) and
+// tracePath (src/main.cpp:160-268).  The order of random draws is part of the
+// contract: light r1, light phi, lobe, then two (or three) draws of the lobe.
+#pragma once
+#include "trace.h"
+
+namespace rtd {
+
+constexpr float kPi = (float)3.141592653589793238462643383279502884197169; // cyCore.h:262
+
+enum { LOBE_NONE = 0, LOBE_DIFFUSE = 1, LOBE_SPECULAR = 2, LOBE_TRANSMISSION = 4 };
+
+struct Surface {
+    V3 p, n, v; // position, unit shading normal, unit view vector
+    int front;
+};
+struct Sample {
+    V3 dir, mult;
+    float prob, dist;
+    int lobe;
+};
+
+RT_DEV V3 light_radiance(const rt_light &l) { return ld3(l.intensity) / ((kPi)*l.size * l.size); } // lights.h:86
+
+// src/lights.h:208-242
+RT_DEV void light_generate(const rt_light &l, V3 P, Rng &rng, Sample &o)
+{
+    V3 toC = ld3(l.position) - P;
+    const float dist = len(toC);
+    toC = normalize(toC);
+    const float sinMax = l.size / dist;
+    const float cosMax = __fsqrt_rn(1.0f - (sinMax * sinMax));
+    const float r1 = rng_float(rng);
+    const float cosT = 1.0f - r1 + r1 * cosMax;
+    const float sinT = __fsqrt_rn(1.0f - (cosT * cosT));
+    const float phi = 2.0f * kPi * rng_float(rng);
+    const float x = sinT * cosf(phi);
+    const float y = sinT * sinf(phi);
+    const float z = cosT;
+    V3 u, v;
+    orthonormals(toC, u, v);
+    const float hyp = dist;
+    const float adj = hyp * cosT;
+    const float oppSq = (hyp * hyp) - (adj * adj);
+    const float inside = (l.size * l.size) - oppSq;
+    const float tOff = __fsqrt_rn(std_max(0.0f, inside));
+    o.dist = adj - tOff;
+    o.dir = normalize((u * x + v * y) + toC * z);
+    o.mult = light_radiance(l);
+    const float omc = (sinMax * sinMax) / (1.0f + cosMax);
+    o.prob = 1.0f / (2.0f * kPi * omc);
+}
+
+// src/lights.h:243-288
+RT_DEV float light_pdf(const rt_light &l, V3 P, V3 dir)
+{
+    V3 toC = ld3(l.position) - P;
+    const float dist = len(toC);
+    const float dist2 = len2(toC);
+    if ((double)dist < 1e-5) return 0.0f;
+    toC = normalize(toC);
+    const float sinMaxSq = (l.size * l.size) / dist2;
+    const float cosRay = dot(dir, toC);
+    if (cosRay <= 0.0f) return 0.0f;
+    const float cosRaySq = cosRay * cosRay;
+    const float cosMaxSq = 1.0f - sinMaxSq;
+    if (cosRaySq >= cosMaxSq) {
+        const float cosMax = __fsqrt_rn(std_max(0.0f, cosMaxSq));
+        const float omc = sinMaxSq / (1.0f + cosMax);
+        return 1.0f / (2.0f * kPi * omc);
+    }
+    return 0.0f;
+}
+
+RT_DEV float gray(const float *c) { return (c[0] + c[1] + c[2]) / 3.0f; } // cyColor.h:86-87
+
+RT_DEV void lobe_probs(const rt_material &m, float &pd, float &ps, float &pt) // materials.h:93-114
+{
+    pd = gray(m.diffuse); ps = gray(m.specular); pt = gray(m.refraction);
+    const float total = pd + ps + pt;
+    if (total > 1.0f) { pd /= total; ps /= total; pt /= total; }
+}
+
+// src/materials.h:87-264
+RT_DEV bool mtl_generate(const rt_material &m, const Surface &s, Rng &rng, Sample &o)
+{
+    const V3 kd = ld3(m.diffuse), ks = ld3(m.specular), kt = ld3(m.refraction);
+    float pd, ps, pt;
+    lobe_probs(m, pd, ps, pt);
+    const V3 Ns = s.n, V = s.v;
+    o.dist = 0.0f;
+    const float rnd = rng_float(rng);
+    if (rnd < pd) {
+        o.lobe = LOBE_DIFFUSE;
+        const float r = __fsqrt_rn(rng_float(rng));
+        const float theta = 2.0f * kPi * rng_float(rng);
+        const float x = r * cosf(theta);
+        const float y = r * sinf(theta);
+        const float z = __fsqrt_rn(std_max(0.0f, 1.0f - x * x - y * y));
+        V3 u, v;
+        orthonormals(Ns, u, v);
+        const V3 dir = (u * x + v * y) + Ns * z;
+        const float g = std_max(0.0f, dot(Ns, dir));
+        o.dir = dir;
+        o.mult = (kd * g) / kPi;
+        o.prob = (g / kPi) * pd;
+        return true;
+    }
+    if (rnd < pd + ps) {
+        o.lobe = LOBE_SPECULAR;
+        const float alpha = m.glossiness;
+        const float phi = 2.0f * kPi * rng_float(rng);
+        const float cosT = powf(1.0f - rng_float(rng), 1.0f / (alpha + 1.0f));
+        const float sinT = __fsqrt_rn(1.0f - cosT * cosT);
+        const float x = sinT * cosf(phi);
+        const float y = sinT * sinf(phi);
+        V3 u, v;
+        orthonormals(Ns, u, v);
+        const V3 h = (u * x + v * y) + Ns * cosT;
+        const float vh = dot(V, h);
+        o.dir = normalize((h * 2.0f) * std_max(0.0f, vh) - V);
+        const float nDotH = dot(Ns, h);
+        if (nDotH < 0.0f) return false;
+        const float pdfH = ((alpha + 1.0f) / (8.0f * kPi)) * powf(cosT, alpha);
+        o.prob = (pdfH / (4.0f * vh)) * ps;
+        const float specNorm = (alpha + 2.0f) / (8.0f * kPi);
+        o.mult = ((ks * specNorm) * powf(nDotH, alpha)) / (4.0f * vh);
+        return true;
+    }
+    if (rnd < pd + ps + pt) {
+        o.lobe = LOBE_TRANSMISSION;
+        const float fresnelRatio = powf((1.0f - m.ior) / (1.0f + m.ior), 2.0f);
+        V3 N = Ns;
+        float etaI = 1.0f, etaT = m.ior;
+        if (!s.front) { N = -N; const float t = etaI; etaI = etaT; etaT = t; }
+        const float eta = etaI / etaT;
+        const float alpha = m.glossiness;
+        const float phi = 2.0f * kPi * rng_float(rng);
+        const float cosT = powf(1.0f - rng_float(rng), 1.0f / (alpha + 1.0f));
+        const float sinT = __fsqrt_rn(1.0f - cosT * cosT);
+        const float x = sinT * cosf(phi);
+        const float y = sinT * sinf(phi);
+        V3 u, v;
+        orthonormals(N, u, v);
+        const V3 h = (u * x + v * y) + N * cosT;
+        const float vDotH = dot(V, h);
+        const float k = 1.0f - eta * eta * (1.0f - vDotH * vDotH);
+        o.mult = kt;
+        o.prob = pt;
+        const V3 refl = (h * 2.0f) * std_max(0.0f, vDotH) - V;
+        if (k < 0.0f) { o.dir = refl; return true; }
+        const V3 dir = h * (eta * vDotH - __fsqrt_rn(k)) - V * eta;
+        o.dir = dir;
+        if (fabsf(dot(N, dir)) < 1e-5f) return false;
+        const float F = fresnelRatio + (1.0f - fresnelRatio) * powf(1.0f - vDotH, 5.0f);
+        const float tf = 1.0f - F;
+        if (rng_float(rng) > tf) o.dir = refl;
+        return true;
+    }
+    return false;
+}
+
+// src/materials.h:266-303
+RT_DEV float mtl_pdf(const rt_material &m, const Surface &s, V3 dir)
+{
+    float pd, ps, pt;
+    lobe_probs(m, pd, ps, pt);
+    const float nDotDir = dot(s.n, dir);
+    const bool isRefl = nDotDir > 0.0f;
+    float prob = 0.0f;
+    if (pd > 0.0f && isRefl) prob += pd * (nDotDir / kPi);
+    const V3 h = normalize(s.v + dir);
+    const float nDotH = dot(s.n, h);
+    const float vDotH = dot(s.v, h);
+    if (isRefl && nDotH > 0.0f && vDotH > 0.0f && ps > 0.0f) {
+        const float alpha = m.glossiness;
+        const float specNorm = (alpha + 2.0f) / (8.0f * kPi);
+        const float pdfH = specNorm * powf(nDotH, alpha);
+        prob += ps * (pdfH / (4.0f * vDotH));
+    }
+    return prob;
+}
+
+struct PathTally {
+    uint32_t closest = 0, shadow = 0;
+};
+
+// tracePath (src/main.cpp:160-268).  first_hit receives z and node id of the
+// first closest-hit query when non-null (used for the depth / id planes).
+template <bool COUNT>
+RT_DEV V3 trace_path(const DScene &S, const DFrame &F, Ray ray, Rng &rng, LaneStack st, PathTally &pt,
+                     Tally<COUNT> &tl, float *first_z, int *first_id)
+{
+    V3 throughput = mk(1.0f, 1.0f, 1.0f);
+    V3 result = mk(0.0f, 0.0f, 0.0f);
+    const rt_light &light = S.lights[0];
+    const float bias = F.bias;
+    float lastProb = 1.0f;
+    int lastLobe = LOBE_NONE;
+    for (int bounce = 0; bounce < F.max_bounces; ++bounce) {
+        Hit h;
+        ++pt.closest;
+        const bool hit = trace_closest<COUNT>(S, ray, st, h, tl);
+        if (bounce == 0 && first_z) { *first_z = h.z; *first_id = hit ? h.node : -1; }
+        if (!hit) {
+            result = result + ld3(S.background) * throughput; // main.cpp:175-176
+            return result;
+        }
+        if (h.node < 0) { // light (main.cpp:184-210)
+            const V3 rad = light_radiance(light);
+            if (bounce == 0) result = result + rad * throughput;
+            else {
+                float weight = 1.0f;
+                if (lastLobe == LOBE_DIFFUSE) {
+                    const float lp = light_pdf(light, ray.p, ray.d);
+                    if (lp > 0.0f) weight = (lastProb * lastProb) / (lastProb * lastProb + lp * lp);
+                }
+                result = result + (rad * throughput) * weight;
+            }
+            return result;
+        }
+        finish_hit(S, ray, h, false);
+        Surface s; // SamplerInfo::SetHit (renderer.h:145-153)
+        const V3 normal = normalize(h.n);
+        s.p = h.p; s.n = normal; s.v = -normalize(ray.d); s.front = h.front;
+        const rt_material &mtl = S.materials[S.nodes[h.node].material];
+
+        // next-event estimation (main.cpp:214-251)
+        Sample ne;
+        light_generate(light, s.p, rng, ne);
+        {
+            const float sign = h.front ? 1.0f : -1.0f;
+            Ray sr;
+            sr.p = h.p + (normal * bias) * sign;
+            sr.d = ne.dir;
+            ++pt.shadow;
+            if (!trace_shadow<COUNT>(S, sr, ne.dist - bias, st, tl)) {
+                const float cosS = std_max(0.0f, dot(normal, sr.d));
+                if (cosS > 0.0f && ne.prob > 0.0f) {
+                    const float mp = mtl_pdf(mtl, s, ne.dir);
+                    float weight = 1.0f;
+                    if (mp > 0.0f) weight = (ne.prob * ne.prob) / (ne.prob * ne.prob + mp * mp);
+                    // the specular term of main.cpp:241-246 is gated on a field that
+                    // GetSampleInfo never writes (it reads as NONE): diffuse only
+                    const V3 brdf = ld3(mtl.diffuse) / kPi;
+                    result = result + ((((brdf * cosS) * ne.mult) * weight) / ne.prob) * throughput;
+                }
+            }
+        }
+
+        // indirect bounce (main.cpp:253-264)
+        Sample in;
+        if (!mtl_generate(mtl, s, rng, in)) break;
+        lastProb = in.prob;
+        lastLobe = in.lobe;
+        ray.d = in.dir;
+        const float sign = (dot(normal, ray.d) > 0.0f) ? 1.0f : -1.0f;
+        ray.p = h.p + (normal * bias) * sign;
+        throughput = throughput * (in.mult / in.prob);
+    }
+    return result;
+}
+
+} // namespace rtd

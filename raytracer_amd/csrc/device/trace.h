@@ -1,0 +1,410 @@
+// Closest-hit and any-hit queries against the flattened scene: the device form of
+// Renderer::TraceRay / TraceShadowRay (src/main.cpp:16-125) with the Sphere,
+// Plane and TriObj intersectors (src/Sphere.cpp, src/Plane.cpp, src/TriObj.cpp)
+// and the spherical-light intersector (src/lights.h:129-156).
+//
+// One lane = one ray.  The scene-graph recursion of the reference becomes a loop
+// over the depth-first node list: the loop index is wave-uniform, so node
+// matrices arrive through scalar loads, and the per-level local rays live in
+// registers selected by the (uniform) node depth.  The BVH stack of a lane lives
+// in LDS as stack[level][thread]: 256 threads * 4 bytes is a multiple of the bank
+// row, so lanes at different stack levels never collide on a bank.
+#pragma once
+#include "dmath.h"
+#include "scene_dev.h"
+#include <float.h>
+
+namespace rtd {
+
+struct Hit {
+    float z;       // ray parameter, FLT_MAX = none
+    int node;      // pre-order node index, -1 none, -2-l light l
+    int front;
+    V3 p, n, uvw;  // filled by finish_hit for the winning object only
+    // winner bookkeeping until finish_hit
+    uint32_t face;
+    float u, v;
+};
+
+struct LaneStack {
+    uint32_t *id; // &lds_ids[threadIdx.x], stride blockDim.x
+    float *t;     // &lds_t[threadIdx.x]
+    uint32_t stride;
+};
+
+template <bool COUNT> struct Tally {
+    uint32_t box = 0, tri = 0;
+    RT_DEV void boxes(uint32_t n) { if (COUNT) box += n; }
+    RT_DEV void tris(uint32_t n) { if (COUNT) tri += n; }
+};
+
+// ---- node transforms (scene.h:186-192) ----
+RT_DEV Ray to_node(const DNode &n, Ray r)
+{
+    Ray o;
+    o.p = m34_mul(n.itm, r.p);
+    o.d = m3_mul(n.itm, r.d);
+    return o;
+}
+
+// ---- sphere (src/Sphere.cpp:7-18,57-88 and 93-110) ----
+RT_DEV bool sphere_t(Ray r, float &t, int &front)
+{
+    const float a = dot(r.d, r.d);
+    const float b = 2 * dot(r.d, r.p);
+    const float c = dot(r.p, r.p) - 1.0f;
+    const float disc = b * b - 4 * a * c;
+    if (disc < 0.0f) return false;
+    const float s = __fsqrt_rn(disc);
+    const float inv2a = 1.0f / (2.0f * a);
+    const float t1 = (-b - s) * inv2a;
+    const float t2 = (-b + s) * inv2a;
+    if (t1 < 0.0f && t2 < 0.0f) return false;
+    if (t1 > 0.0f) { t = t1; front = 1; }
+    else { t = t2; front = 0; }
+    return true;
+}
+RT_DEV bool sphere_shadow(Ray r, float t_max)
+{
+    const float a = dot(r.d, r.d);
+    const float b = 2 * dot(r.d, r.p);
+    const float c = dot(r.p, r.p) - 1.0f;
+    const float disc = b * b - 4 * a * c;
+    if (disc < 0.0f) return false;
+    const float s = __fsqrt_rn(disc);
+    const float inv2a = 1.0f / (2.0f * a);
+    const float t1 = (-b - s) * inv2a;
+    const float t2 = (-b + s) * inv2a;
+    if (t1 >= 0.0f) return t1 < t_max;
+    return t2 >= 0.0f && t2 < t_max;
+}
+
+// ---- plane (src/Plane.cpp:7-36) ----
+RT_DEV bool plane_t(Ray r, float &t, int &front)
+{
+    if (fabsf(r.d.z) < 1e-6f) return false;
+    const float tt = -r.p.z / r.d.z;
+    if (tt < 0.0f) return false;
+    const V3 pos = r.p + r.d * tt;
+    if (fabsf(pos.x) > 1.0f || fabsf(pos.y) > 1.0f) return false;
+    t = tt;
+    front = r.d.z < 0.0f;
+    return true;
+}
+RT_DEV bool plane_shadow(Ray r, float t_max)
+{
+    float t; int front;
+    if (!plane_t(r, t, front)) return false;
+    return t < t_max;
+}
+
+// ---- BVH slab test (src/TriObj.cpp:272-320); inv = 1/dir computed once per ray ----
+RT_DEV bool bvh_box(V3 p, V3 inv, float t_max, float4 b0, float4 b1, float &dist)
+{
+    float tNear = 0.0f;
+    float tFar = t_max;
+    float t1 = (b0.x - p.x) * inv.x;
+    float t2 = (b0.w - p.x) * inv.x;
+    float smin = std_min(t1, t2);
+    float smax = std_max(t2, t1);
+    tNear = std_max(tNear, smin);
+    tFar = std_min(tFar, smax);
+    if (tNear > tFar) return false;
+    t1 = (b0.y - p.y) * inv.y;
+    t2 = (b1.x - p.y) * inv.y;
+    smin = std_min(t1, t2);
+    smax = std_max(t1, t2);
+    tNear = std_max(tNear, smin);
+    tFar = std_min(tFar, smax);
+    if (tNear > tFar) return false;
+    t1 = (b0.z - p.z) * inv.z;
+    t2 = (b1.y - p.z) * inv.z;
+    smin = std_min(t1, t2);
+    smax = std_max(t1, t2);
+    tNear = std_max(tNear, smin);
+    tFar = std_min(tFar, smax);
+    if (tNear > tFar) return false;
+    if (tNear < tFar) { dist = tNear; return true; }
+    return false;
+}
+
+// one Moeller-Trumbore test (src/TriObj.cpp:46-74) up to, not including, the range test on t
+RT_DEV bool tri_test(const float4 *rec, Ray r, float &t, float &u, float &v, float &det, uint32_t &face)
+{
+    const float epsilon = 1e-6f;
+    const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+    const V3 v0 = mk(q0.x, q0.y, q0.z), v1 = mk(q0.w, q1.x, q1.y), v2 = mk(q1.z, q1.w, q2.x);
+    face = __float_as_uint(q2.y);
+    const V3 e1 = v1 - v0;
+    const V3 e2 = v2 - v0;
+    const V3 rxe2 = cross(r.d, e2);
+    det = dot(e1, rxe2);
+    if (det > -epsilon && det < epsilon) return false;
+    const float invDet = 1.0f / det;
+    const V3 s = r.p - v0;
+    u = invDet * dot(s, rxe2);
+    if (u < 0.0f || u > 1.0f) return false;
+    const V3 sxe1 = cross(s, e1);
+    v = invDet * dot(r.d, sxe1);
+    if (v < 0.0f || u + v > 1.0f) return false;
+    t = invDet * dot(e2, sxe1);
+    return true;
+}
+
+constexpr uint32_t kLeafBit = 0x80000000u;
+
+// TriObj::IntersectRay (src/TriObj.cpp:12-137) without the final attribute
+// interpolation: same node order, same pruning, same tie rules.
+template <bool COUNT>
+RT_DEV bool mesh_closest(const DMesh &M, Ray r, LaneStack st, float &tOut, uint32_t &faceOut, float &uOut,
+                         float &vOut, float &detOut, Tally<COUNT> &tl)
+{
+    const float epsilon = 1e-6f;
+    const V3 inv = mk(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+    float closestT = FLT_MAX;
+    int sp = 0;
+    {
+        float dist;
+        tl.boxes(1);
+        if (!bvh_box(r.p, inv, closestT, M.bvh[2], M.bvh[3], dist)) return false;
+        st.id[0] = 1; st.t[0] = dist; sp = 1;
+    }
+    bool hit = false;
+    while (sp > 0) {
+        --sp;
+        const uint32_t id = st.id[sp * st.stride];
+        const float nodeT = st.t[sp * st.stride];
+        if (closestT < nodeT) continue;
+        const uint32_t data = __float_as_uint(M.bvh[id * 2 + 1].z);
+        if (data & kLeafBit) {
+            const uint32_t off = data & 0x0FFFFFFFu;
+            const uint32_t cnt = ((data >> 28) & 7u) + 1;
+            for (uint32_t i = 0; i < cnt; ++i) {
+                float t, u, v, det; uint32_t face;
+                tl.tris(1);
+                if (!tri_test(&M.tris[(off + i) * 3], r, t, u, v, det, face)) continue;
+                if (t <= epsilon || t > closestT) continue;
+                hit = true; closestT = t; detOut = det; uOut = u; vOut = v; faceOut = face;
+            }
+            continue;
+        }
+        const uint32_t c1 = data & 0x7FFFFFFFu, c2 = c1 + 1;
+        const float4 a0 = M.bvh[c1 * 2], a1 = M.bvh[c1 * 2 + 1], b0 = M.bvh[c2 * 2], b1 = M.bvh[c2 * 2 + 1];
+        float d1, d2;
+        tl.boxes(2);
+        bool h1 = bvh_box(r.p, inv, closestT, a0, a1, d1);
+        h1 = h1 && d1 < closestT;
+        bool h2 = bvh_box(r.p, inv, closestT, b0, b1, d2);
+        h2 = h2 && d2 < closestT;
+        if (!h1 && !h2) continue;
+        if (h1 && h2) {
+            // nearer child on top of the stack; on a tie the second child is visited first
+            const bool firstNear = d1 < d2;
+            st.id[sp * st.stride] = firstNear ? c2 : c1; st.t[sp * st.stride] = firstNear ? d2 : d1; ++sp;
+            st.id[sp * st.stride] = firstNear ? c1 : c2; st.t[sp * st.stride] = firstNear ? d1 : d2; ++sp;
+            continue;
+        }
+        st.id[sp * st.stride] = h1 ? c1 : c2; st.t[sp * st.stride] = h1 ? d1 : d2; ++sp;
+    }
+    tOut = closestT;
+    return hit;
+}
+
+// TriObj::IntersectShadowRay (src/TriObj.cpp:139-229).  The answer is an
+// existence test, so it does not depend on the visiting order.
+template <bool COUNT>
+RT_DEV bool mesh_shadow(const DMesh &M, Ray r, float t_max, LaneStack st, Tally<COUNT> &tl)
+{
+    const float epsilon = 1e-6f;
+    const V3 inv = mk(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+    int sp = 0;
+    {
+        float dist;
+        tl.boxes(1);
+        if (!bvh_box(r.p, inv, t_max, M.bvh[2], M.bvh[3], dist)) return false;
+        st.id[0] = 1; sp = 1;
+    }
+    while (sp > 0) {
+        --sp;
+        const uint32_t id = st.id[sp * st.stride];
+        const uint32_t data = __float_as_uint(M.bvh[id * 2 + 1].z);
+        if (data & kLeafBit) {
+            const uint32_t off = data & 0x0FFFFFFFu;
+            const uint32_t cnt = ((data >> 28) & 7u) + 1;
+            for (uint32_t i = 0; i < cnt; ++i) {
+                float t, u, v, det; uint32_t face;
+                tl.tris(1);
+                if (!tri_test(&M.tris[(off + i) * 3], r, t, u, v, det, face)) continue;
+                if (t <= epsilon || t > t_max) continue;
+                return true;
+            }
+            continue;
+        }
+        const uint32_t c1 = data & 0x7FFFFFFFu, c2 = c1 + 1;
+        const float4 a0 = M.bvh[c1 * 2], a1 = M.bvh[c1 * 2 + 1], b0 = M.bvh[c2 * 2], b1 = M.bvh[c2 * 2 + 1];
+        float d1, d2;
+        tl.boxes(2);
+        const bool h1 = bvh_box(r.p, inv, t_max, a0, a1, d1);
+        const bool h2 = bvh_box(r.p, inv, t_max, b0, b1, d2);
+        if (!h1 && !h2) continue;
+        if (h1 && h2) {
+            const bool firstNear = d1 < d2;
+            st.id[sp * st.stride] = firstNear ? c2 : c1; ++sp;
+            st.id[sp * st.stride] = firstNear ? c1 : c2; ++sp;
+            continue;
+        }
+        st.id[sp * st.stride] = h1 ? c1 : c2; ++sp;
+    }
+    return false;
+}
+
+// per-level local rays, selected by the wave-uniform node depth.  Value selects
+// on named members (no array, no conditional stores) keep every level in registers.
+RT_DEV float selq(bool c, float a, float b) { return c ? a : b; }
+RT_DEV Ray sel(bool c, Ray a, Ray b)
+{
+    Ray o;
+    o.p = mk(selq(c, a.p.x, b.p.x), selq(c, a.p.y, b.p.y), selq(c, a.p.z, b.p.z));
+    o.d = mk(selq(c, a.d.x, b.d.x), selq(c, a.d.y, b.d.y), selq(c, a.d.z, b.d.z));
+    return o;
+}
+struct RayLevels {
+    Ray r0, r1, r2, r3, r4;
+    static_assert(kMaxSceneDepth == 6, "levels 0..4 can be parents; level 5 is always a leaf level");
+    // local ray of the node at depth d (d <= 4)
+    RT_DEV Ray get(int d) const
+    {
+        Ray o = r0;
+        o = sel(d == 1, r1, o);
+        o = sel(d == 2, r2, o);
+        o = sel(d == 3, r3, o);
+        o = sel(d == 4, r4, o);
+        return o;
+    }
+    RT_DEV void set(int d, Ray v)
+    {
+        r0 = sel(d == 0, v, r0);
+        r1 = sel(d == 1, v, r1);
+        r2 = sel(d == 2, v, r2);
+        r3 = sel(d == 3, v, r3);
+        r4 = sel(d == 4, v, r4);
+    }
+    RT_DEV void init(Ray v) { r0 = r1 = r2 = r3 = r4 = v; }
+};
+
+// shootRay + shootRayAtLights (src/main.cpp:16-70,115-120).  The winner is the
+// first hit in depth-first order with the smallest z (strict <), which is what
+// the reference's per-level comparisons select.
+template <bool COUNT>
+RT_DEV bool trace_closest(const DScene &S, Ray ray, LaneStack st, Hit &h, Tally<COUNT> &tl)
+{
+    h.z = FLT_MAX; h.node = -1; h.front = 1; h.face = 0; h.u = 0; h.v = 0;
+    RayLevels lv;
+    lv.init(ray);
+    const int n = S.n_nodes;
+    for (int i = 0; i < n; ++i) {
+        const DNode &nd = S.nodes[i];
+        const int d = nd.depth;
+        const Ray parent = (d == 0) ? ray : lv.get(d - 1);
+        const Ray lr = to_node(nd, parent);
+        if (nd.has_children) lv.set(d, lr);
+        const int prim = nd.prim;
+        if (prim == RT_PRIM_NONE) continue;
+        float t = 0; int front = 1; bool ok = false;
+        uint32_t face = 0; float u = 0, v = 0;
+        if (prim == RT_PRIM_SPHERE) ok = sphere_t(lr, t, front);
+        else if (prim == RT_PRIM_PLANE) ok = plane_t(lr, t, front);
+        else {
+            float det = 0;
+            ok = mesh_closest<COUNT>(S.meshes[nd.mesh], lr, st, t, face, u, v, det, tl);
+            front = det > 0.0f;
+        }
+        if (ok && t < h.z) { h.z = t; h.node = i; h.front = front; h.face = face; h.u = u; h.v = v; }
+    }
+    bool hit = h.node >= 0;
+    // spherical lights, front side only (src/lights.h:129-156 via the default hitSide of scene.h:273)
+    for (int l = 0; l < S.n_lights; ++l) {
+        const rt_light &L = S.lights[l];
+        if (L.type != RT_LIGHT_POINT) continue;
+        Ray r;
+        r.p = (ray.p - ld3(L.position)) / L.size;
+        r.d = ray.d / L.size;
+        const float a = dot(r.d, r.d);
+        const float b = 2 * dot(r.d, r.p);
+        const float c = dot(r.p, r.p) - 1.0f;
+        const float disc = b * b - 4 * a * c;
+        if (disc < 0.0f) continue;
+        const float s = __fsqrt_rn(disc);
+        const float inv2a = 1.0f / (2.0f * a);
+        const float t1 = (-b - s) * inv2a;
+        if (t1 <= 0.0f) continue;
+        if (t1 < h.z) { h.z = t1; h.node = -2 - l; h.front = 1; hit = true; break; }
+    }
+    return hit;
+}
+
+// Hit attributes of the winning object, then its way back up the hierarchy
+// (src/Sphere.cpp:64-70, src/Plane.cpp:17-21, src/TriObj.cpp:126-134, scene.h:187-192).
+// p, N are world space; N is not normalised.
+RT_DEV void finish_hit(const DScene &S, Ray ray, Hit &h, bool want_uvw)
+{
+    if (h.node < 0) { h.p = mk(0, 0, 0); h.n = mk(0, 0, 0); h.uvw = mk(0.5f, 0.5f, 0.5f); return; }
+    // rebuild the local ray of the winning node through its ancestor chain, root first
+    const DNode &nd = S.nodes[h.node];
+    const int depth = nd.depth;
+    Ray lr = ray;
+    for (int k = 0; k <= depth; ++k) lr = to_node(S.nodes[nd.chain[k]], lr);
+    h.p = lr.p + lr.d * h.z;
+    h.uvw = mk(0.5f, 0.5f, 0.5f);
+    if (nd.prim == RT_PRIM_SPHERE) {
+        h.n = h.p;
+        if (want_uvw) {
+            const float u = (float)((1.0f / (2.0f * (float)M_PI)) * atan2((double)h.p.y, (double)h.p.x) + 0.5f);
+            const float v = (float)((1.0f / (float)M_PI * asin((double)h.p.z) + 0.5f));
+            h.uvw = mk(u, v, 1.0f);
+        }
+    } else if (nd.prim == RT_PRIM_PLANE) {
+        h.n = mk(0.0f, 0.0f, 1.0f);
+        h.uvw = h.p * 0.5f + mk(1.0f, 1.0f, 1.0f);
+    } else {
+        const DMesh &M = S.meshes[nd.mesh];
+        const uint32_t *nf = &M.fn[h.face * 3];
+        const float w = 1.0f - h.u - h.v;
+        h.n = normalize((ld3(&M.vn[nf[0] * 3]) * w + ld3(&M.vn[nf[1] * 3]) * h.u) + ld3(&M.vn[nf[2] * 3]) * h.v);
+        if (want_uvw) {
+            const uint32_t *tf = &M.ft[h.face * 3];
+            h.uvw = (ld3(&M.vt[tf[0] * 3]) * w + ld3(&M.vt[tf[1] * 3]) * h.u) + ld3(&M.vt[tf[2] * 3]) * h.v;
+        }
+    }
+    for (int k = depth; k >= 0; --k) {
+        const DNode &a = S.nodes[nd.chain[k]];
+        h.p = m34_mul(a.tm, h.p);
+        h.n = m3_tmul(a.itm, h.n);
+    }
+}
+
+// shootShadowRay (src/main.cpp:72-89,122-125): any hit with t < t_max
+template <bool COUNT>
+RT_DEV bool trace_shadow(const DScene &S, Ray ray, float t_max, LaneStack st, Tally<COUNT> &tl)
+{
+    RayLevels lv;
+    lv.init(ray);
+    const int n = S.n_nodes;
+    for (int i = 0; i < n; ++i) {
+        const DNode &nd = S.nodes[i];
+        const int d = nd.depth;
+        const Ray parent = (d == 0) ? ray : lv.get(d - 1);
+        const Ray lr = to_node(nd, parent);
+        if (nd.has_children) lv.set(d, lr);
+        const int prim = nd.prim;
+        if (prim == RT_PRIM_NONE) continue;
+        bool occ;
+        if (prim == RT_PRIM_SPHERE) occ = sphere_shadow(lr, t_max);
+        else if (prim == RT_PRIM_PLANE) occ = plane_shadow(lr, t_max);
+        else occ = mesh_shadow<COUNT>(S.meshes[nd.mesh], lr, t_max, st, tl);
+        if (occ) return true;
+    }
+    return false;
+}
+
+} // namespace rtd

@@ -1,0 +1,297 @@
+// scene.xml -> flattened scene.  Follows the reference's loader rule for rule
+// (src/xmlload.cpp:41-270, src/xmlload.h:58-63) so that a scene file means the
+// same thing on both sides of the C ABI: same defaults, same attribute
+// handling, same order of transform composition, nodes in depth-first order.
+#include "scene_host.h"
+#include "xform.h"
+#include "xml_reader.h"
+
+#include <cctype>
+#include <cstdlib>
+#include <cstring>
+#include <sys/stat.h>
+
+void rt_scene_host::refresh_desc()
+{
+    mesh_descs.clear();
+    for (auto &m : meshes) mesh_descs.push_back(m->desc());
+    desc.nodes = nodes.data(); desc.n_nodes = (uint32_t)nodes.size();
+    desc.meshes = mesh_descs.data(); desc.n_meshes = (uint32_t)mesh_descs.size();
+    desc.materials = materials.data(); desc.n_materials = (uint32_t)materials.size();
+    desc.lights = lights.data(); desc.n_lights = (uint32_t)lights.size();
+}
+
+namespace rt {
+namespace {
+
+// case-insensitive string equality, as the reference compares tags and type names (xmlload.h:46-52)
+bool ieq(const char *a, const char *b)
+{
+    if (a == b) return true;
+    if (!a || !b) return false;
+    for (;; ++a, ++b) {
+        if (tolower((unsigned char)*a) != tolower((unsigned char)*b)) return false;
+        if (*a == '\0') return true;
+    }
+}
+
+bool read_float(const XmlElement *e, float &f, const char *name = "value")
+{
+    if (!e) return false;
+    const char *s = e->attr(name);
+    if (!s) return false;
+    float v;
+    if (sscanf(s, "%f", &v) != 1) return false;
+    f = v;
+    return true;
+}
+bool read_int(const XmlElement *e, int &i, const char *name = "value")
+{
+    if (!e) return false;
+    const char *s = e->attr(name);
+    if (!s) return false;
+    char *end;
+    long v = strtol(s, &end, 0);
+    if (end == s) return false;
+    i = (int)v;
+    return true;
+}
+// x,y,z attributes over a default, then multiplied by `value` when present
+void read_vec3(const XmlElement *e, Vec3 &v, Vec3 def = {0, 0, 0})
+{
+    if (!e) return;
+    v = def;
+    read_float(e, v.x, "x"); read_float(e, v.y, "y"); read_float(e, v.z, "z");
+    float f = 1;
+    if (read_float(e, f)) v = v * f;
+}
+void read_color(const XmlElement *e, float c[3], Vec3 def = {1, 1, 1})
+{
+    if (!e) return;
+    Vec3 v = def;
+    read_float(e, v.x, "r"); read_float(e, v.y, "g"); read_float(e, v.z, "b");
+    float f = 1;
+    if (read_float(e, f)) v = v * f;
+    c[0] = v.x; c[1] = v.y; c[2] = v.z;
+}
+
+struct Loader {
+    rt_scene_host &S;
+    std::string base_dir;
+    std::string err;
+    std::vector<std::string> node_material_names; // per node, "" = none
+
+    bool file_exists(const std::string &p) { struct stat st; return stat(p.c_str(), &st) == 0; }
+
+    void textured(const XmlElement *e, const char *what)
+    {
+        if (e && e->attr("texture"))
+            S.warnings.push_back(std::string("texture on <") + what + "> ignored: textures are not part of the accelerated path");
+    }
+
+    // Transformation::Load (xmlload.cpp:173-193): each child element pre-multiplies the node matrix
+    void load_transform(const XmlElement &e, Mat34 &tm, Mat34 &itm)
+    {
+        for (auto &c : e.children) {
+            Mat34 m;
+            if (ieq(c->tag.c_str(), "scale")) {
+                Vec3 s; read_vec3(c.get(), s, {1, 1, 1});
+                m = Mat34::scale(s);
+            } else if (ieq(c->tag.c_str(), "rotate")) {
+                Vec3 s{0, 0, 0}; read_vec3(c.get(), s);
+                s = normalized(s);
+                float a = 0.0f; read_float(c.get(), a, "angle");
+                const float pi = (float)3.141592653589793238462643383279502884197169;
+                m = Mat34::rotation(s, a * (pi / 180.0f));
+            } else if (ieq(c->tag.c_str(), "translate")) {
+                Vec3 t{0, 0, 0}; read_vec3(c.get(), t);
+                m = Mat34::translation(t);
+            } else continue;
+            tm = m * tm;
+            itm = tm.inverse();
+        }
+    }
+
+    int find_mesh(const std::string &name)
+    {
+        for (size_t i = 0; i < S.meshes.size(); ++i) if (S.meshes[i]->name == name) return (int)i;
+        return -1;
+    }
+
+    // LoadNode (xmlload.cpp:124-169)
+    bool load_node(const XmlElement &e, int parent)
+    {
+        rt_node n{};
+        Mat34 tm = Mat34::identity(), itm = Mat34::identity();
+        n.parent = parent; n.prim = RT_PRIM_NONE; n.mesh = -1; n.material = -1;
+        const char *name = e.attr("name");
+        const char *mtl = e.attr("material");
+        const char *type = e.attr("type");
+        if (type) {
+            if (ieq(type, "sphere")) n.prim = RT_PRIM_SPHERE;
+            else if (ieq(type, "plane")) n.prim = RT_PRIM_PLANE;
+            else if (ieq(type, "obj")) {
+                const std::string nm = name ? name : "";
+                int mi = find_mesh(nm);
+                if (mi < 0) {
+                    auto m = std::make_unique<HostMesh>();
+                    m->name = nm;
+                    std::string path = nm;
+                    if (!file_exists(path) && !base_dir.empty()) path = base_dir + "/" + nm;
+                    if (file_exists(path)) {
+                        if (!load_obj(path, *m, err)) return false;
+                        build_bvh(m->v.data(), m->f.data(), m->nf(), 4, m->bvh, m->elements, m->depth);
+                    }
+                    // a mesh whose file is absent stays empty until rt_scene_host_set_mesh fills it
+                    S.meshes.push_back(std::move(m));
+                    mi = (int)S.meshes.size() - 1;
+                }
+                n.prim = RT_PRIM_MESH;
+                n.mesh = mi;
+            } else S.warnings.push_back(std::string("unknown object type ") + type);
+        }
+        load_transform(e, tm, itm);
+        memcpy(n.tm, tm.c, sizeof n.tm);
+        memcpy(n.itm, itm.c, sizeof n.itm);
+        const int me = (int)S.nodes.size();
+        S.nodes.push_back(n);
+        S.node_names.push_back(name ? name : "");
+        node_material_names.push_back(mtl ? mtl : "");
+        for (auto &c : e.children)
+            if (ieq(c->tag.c_str(), "object") && !load_node(*c, me)) return false;
+        return true;
+    }
+
+    void load_light(const XmlElement &e)
+    {
+        const char *type = e.attr("type");
+        rt_light l{};
+        if (ieq(type, "ambient")) {
+            l.type = RT_LIGHT_AMBIENT;
+            read_color(e.child("intensity"), l.intensity);
+        } else if (ieq(type, "direct")) {
+            l.type = RT_LIGHT_DIRECT;
+            read_color(e.child("intensity"), l.intensity);
+            Vec3 d{0, 0, 0}; read_vec3(e.child("direction"), d);
+            d = normalized(d);
+            l.direction[0] = d.x; l.direction[1] = d.y; l.direction[2] = d.z;
+        } else if (ieq(type, "point")) {
+            l.type = RT_LIGHT_POINT;
+            read_color(e.child("intensity"), l.intensity);
+            Vec3 p{0, 0, 0}; read_vec3(e.child("position"), p);
+            l.position[0] = p.x; l.position[1] = p.y; l.position[2] = p.z;
+            read_float(e.child("size"), l.size);
+            read_float(e.child("attenuation"), l.attenuation);
+        } else {
+            S.warnings.push_back(std::string("unknown light type ") + (type ? type : "(none)"));
+            return;
+        }
+        S.lights.push_back(l);
+    }
+
+    // LoadMaterial + MtlBasePhongBlinn::Load (xmlload.cpp:242-270), defaults from materials.h:53-60
+    void load_material(const XmlElement &e)
+    {
+        const char *type = e.attr("type");
+        if (!ieq(type, "blinn")) {
+            S.warnings.push_back(std::string("unknown material type ") + (type ? type : "(none)"));
+            return;
+        }
+        rt_material m{};
+        for (int i = 0; i < 3; ++i) { m.diffuse[i] = 0.5f; m.specular[i] = 0.7f; }
+        m.glossiness = 20.0f;
+        m.ior = 1.5f;
+        read_color(e.child("diffuse"), m.diffuse);       textured(e.child("diffuse"), "diffuse");
+        read_color(e.child("specular"), m.specular);     textured(e.child("specular"), "specular");
+        if (const XmlElement *g = e.child("glossiness")) { float f = 1.0f; read_float(g, f); m.glossiness = f; textured(g, "glossiness"); }
+        read_color(e.child("emission"), m.emission);     textured(e.child("emission"), "emission");
+        read_color(e.child("reflection"), m.reflection); textured(e.child("reflection"), "reflection");
+        read_color(e.child("refraction"), m.refraction); textured(e.child("refraction"), "refraction");
+        read_float(e.child("refraction"), m.ior, "index");
+        read_color(e.child("absorption"), m.absorption);
+        S.materials.push_back(m);
+        const char *name = e.attr("name");
+        S.material_names.push_back(name ? name : "");
+    }
+
+    // Camera::Load (xmlload.cpp:104-120), defaults from scene.h:466-477
+    void load_camera(const XmlElement &e)
+    {
+        Vec3 pos{0, 0, 0}, dir{0, 0, -1}, up{0, 1, 0};
+        rt_camera &c = S.camera;
+        c.fov = 40; c.focaldist = 1; c.dof = 0; c.width = 1920; c.height = 1080;
+        read_vec3(e.child("position"), pos);
+        read_vec3(e.child("target"), dir);
+        read_vec3(e.child("up"), up);
+        read_float(e.child("fov"), c.fov);
+        read_float(e.child("focaldist"), c.focaldist);
+        read_float(e.child("dof"), c.dof);
+        read_int(e.child("width"), c.width);
+        read_int(e.child("height"), c.height);
+        dir = dir - pos;
+        dir = normalized(dir);
+        const Vec3 x = cross(dir, up);
+        up = normalized(cross(x, dir));
+        c.pos[0] = pos.x; c.pos[1] = pos.y; c.pos[2] = pos.z;
+        c.dir[0] = dir.x; c.dir[1] = dir.y; c.dir[2] = dir.z;
+        c.up[0] = up.x; c.up[1] = up.y; c.up[2] = up.z;
+        c.srgb = ieq(e.attr("gamma"), "sRGB") ? 1 : 0;
+    }
+
+    bool load(const std::string &xml)
+    {
+        std::unique_ptr<XmlElement> doc = xml_parse(xml, err);
+        if (!doc) return false;
+        const XmlElement *x = doc->child("xml");
+        if (!x) { err = "no \"xml\" tag found"; return false; }
+        const XmlElement *xscene = x->child("scene");
+        if (!xscene) { err = "no \"scene\" tag found"; return false; }
+        const XmlElement *xcam = x->child("camera");
+        if (!xcam) { err = "no \"camera\" tag found"; return false; }
+
+        // root node: identity transform, no object (scene.h:424,497)
+        rt_node root{};
+        memcpy(root.tm, Mat34::identity().c, sizeof root.tm);
+        memcpy(root.itm, Mat34::identity().c, sizeof root.itm);
+        root.parent = -1; root.prim = RT_PRIM_NONE; root.mesh = -1; root.material = -1;
+        S.nodes.push_back(root);
+        S.node_names.push_back("");
+        node_material_names.push_back("");
+
+        // Scene::Load (xmlload.cpp:80-100). The reference appends every top-level
+        // object to the root in file order; nested objects follow their parent, so a
+        // depth-first listing needs the top-level objects visited in file order.
+        for (auto &c : xscene->children) {
+            const char *t = c->tag.c_str();
+            if (ieq(t, "object")) { if (!load_node(*c, 0)) return false; }
+            else if (ieq(t, "light")) load_light(*c);
+            else if (ieq(t, "material")) load_material(*c);
+            else if (ieq(t, "background")) { read_color(c.get(), S.desc.background); textured(c.get(), "background"); }
+            else if (ieq(t, "environment")) { read_color(c.get(), S.desc.environment); textured(c.get(), "environment"); }
+            else S.warnings.push_back(std::string("unknown tag ") + t);
+        }
+        // SetNodeMaterials (xmlload.cpp:274-294): names resolved after all materials are known, exact match
+        for (size_t i = 0; i < S.nodes.size(); ++i) {
+            const std::string &mn = node_material_names[i];
+            if (mn.empty()) continue;
+            for (size_t k = 0; k < S.material_names.size(); ++k)
+                if (S.material_names[k] == mn) { S.nodes[i].material = (int)k; break; }
+        }
+        load_camera(*xcam);
+        S.refresh_desc();
+        return true;
+    }
+};
+
+} // namespace
+
+bool load_scene_xml(const std::string &xml, const std::string &base_dir, rt_scene_host &out, std::string &err)
+{
+    Loader L{out, base_dir, {}, {}};
+    // TexturedColor default-constructs to black (scene.h:376)
+    for (int i = 0; i < 3; ++i) out.desc.background[i] = out.desc.environment[i] = 0.0f;
+    if (!L.load(xml)) { err = L.err; return false; }
+    return true;
+}
+
+} // namespace rt

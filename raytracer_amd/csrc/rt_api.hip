@@ -1,0 +1,552 @@
+// C ABI of the GPU backend: context, scene upload, frame rendering, batch queries.
+// Host-side control only; the arithmetic lives in device/*.h.
+#include "device/kernels.h"
+#include "rt_mi355x.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+using namespace rtd;
+
+namespace {
+
+thread_local std::string g_init_error;
+
+struct DeviceBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    ~DeviceBuf() { if (p) (void)hipFree(p); }
+    DeviceBuf() = default;
+    DeviceBuf(const DeviceBuf &) = delete;
+    DeviceBuf &operator=(const DeviceBuf &) = delete;
+    hipError_t reserve(size_t n)
+    {
+        if (n <= bytes) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+        hipError_t e = hipMalloc(&p, n ? n : 1);
+        if (e == hipSuccess) bytes = n;
+        return e;
+    }
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
+} // namespace
+
+struct rt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, evk0 = nullptr, evk1 = nullptr;
+    std::string error;
+    bool counting = false;
+
+    // scene
+    bool have_scene = false;
+    DScene scene{};
+    DeviceBuf d_nodes, d_meshes, d_materials, d_lights;
+    std::vector<std::unique_ptr<DeviceBuf>> mesh_bufs;
+    std::vector<int> host_node_material; // for validation
+    // camera
+    bool have_camera = false;
+    rt_camera camera{};
+    // frame
+    DeviceBuf d_halton, d_active[2], d_next_count, d_state, d_sbuf, d_counters;
+    DeviceBuf d_rgb, d_z, d_cnt, d_id, d_lin; // internal planes when the caller wants host output
+    DeviceBuf d_q_in, d_q_aux, d_q_out;       // batch queries
+    std::vector<int32_t> active_host;
+    int active_key[5] = {-1, -1, -1, -1, -1};
+    rt_counters counters{};
+
+    int fail(int code, const char *fmt, ...)
+    {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        error = buf;
+        return code;
+    }
+};
+
+#define HIP_TRY(ctx, expr)                                                                          \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess) return (ctx)->fail(RT_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+namespace {
+
+// main() of the reference, src/main.cpp:404-414 (host arithmetic, libm tanf)
+void derive_camera(const rt_camera &cam, DFrame &F)
+{
+    auto norm = [](const float *v, float *o) {
+        const float l = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        o[0] = v[0] / l; o[1] = v[1] / l; o[2] = v[2] / l;
+    };
+    auto crossf = [](const float *a, const float *p, float *o) {
+        o[0] = a[1] * p[2] - a[2] * p[1]; o[1] = a[2] * p[0] - a[0] * p[2]; o[2] = a[0] * p[1] - a[1] * p[0];
+    };
+    float camZ[3], camX[3], camY[3], t[3];
+    norm(cam.dir, camZ);
+    for (float &c : camZ) c = -c;
+    crossf(cam.up, camZ, t);
+    norm(t, camX);
+    crossf(camZ, camX, camY);
+    memcpy(F.cam2world, camX, 12); memcpy(F.cam2world + 3, camY, 12); memcpy(F.cam2world + 6, camZ, 12);
+    const float Pi = 3.14159265358979323846f;
+    F.half_h = cam.focaldist * tanf((cam.fov * Pi / 180.0f) / 2.0f);
+    const float aspect = (float)cam.width / (float)cam.height;
+    F.half_w = aspect * F.half_h;
+    F.pixel_size = (F.half_w * 2.0f) / (float)cam.width;
+    memcpy(F.cam_pos, cam.pos, 12);
+    F.focaldist = cam.focaldist; F.dof = cam.dof;
+    F.width = cam.width; F.height = cam.height; F.srgb = cam.srgb;
+}
+
+float halton(int index, int base) // src/rng.h:103-112
+{
+    float r = 0;
+    float f = 1.0f / (float)base;
+    for (int i = index; i > 0; i /= base) {
+        r += f * (float)(i % base);
+        f /= (float)base;
+    }
+    return r;
+}
+
+int validate_params(rt_ctx *ctx, const rt_render_params *p)
+{
+    if (!p) return ctx->fail(RT_ERR_INVALID, "null render params");
+    if (p->mode != RT_MODE_PATH) return ctx->fail(RT_ERR_UNSUPPORTED, "unknown render mode %d", p->mode);
+    if (p->min_spp < 1 || p->max_spp < p->min_spp) return ctx->fail(RT_ERR_INVALID, "need 1 <= min_spp <= max_spp");
+    if (p->max_bounces < 0) return ctx->fail(RT_ERR_INVALID, "max_bounces < 0");
+    if (p->halton_period < 1 || p->halton_period > 64) return ctx->fail(RT_ERR_INVALID, "halton_period must be 1..64");
+    if (p->tile_size < 1) return ctx->fail(RT_ERR_INVALID, "tile_size < 1");
+    if (p->tile_world < 1 || p->tile_rank < 0 || p->tile_rank >= p->tile_world)
+        return ctx->fail(RT_ERR_INVALID, "need 0 <= tile_rank < tile_world");
+    return RT_OK;
+}
+
+void fill_frame(const rt_ctx *ctx, const rt_render_params *p, DFrame &F)
+{
+    memset(&F, 0, sizeof F);
+    derive_camera(ctx->camera, F);
+    F.min_spp = p->min_spp; F.max_spp = p->max_spp; F.delta_max = p->delta_max;
+    F.max_bounces = p->max_bounces; F.bias = p->bias; F.halton_period = p->halton_period; F.seed = p->seed;
+}
+
+size_t stack_lds_bytes(const DScene &S) { return (size_t)S.stack_levels * kBlock * 8; }
+
+} // namespace
+
+extern "C" {
+
+const char *rt_last_error(const rt_ctx *ctx) { return ctx ? ctx->error.c_str() : g_init_error.c_str(); }
+
+int rt_init(int device, rt_ctx **out)
+{
+    if (!out) { g_init_error = "null output pointer"; return RT_ERR_INVALID; }
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) {
+        g_init_error = std::string("no HIP device available: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+        return RT_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= n) { g_init_error = "device ordinal out of range"; return RT_ERR_INVALID; }
+    auto *ctx = new (std::nothrow) rt_ctx();
+    if (!ctx) { g_init_error = "out of host memory"; return RT_ERR_INVALID; }
+    ctx->device = device;
+    auto bail = [&](const char *what, hipError_t err) {
+        g_init_error = std::string(what) + ": " + hipGetErrorString(err);
+        delete ctx;
+        return RT_ERR_HIP;
+    };
+    if ((e = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", e);
+    if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    for (hipEvent_t *ev : {&ctx->ev0, &ctx->ev1, &ctx->evk0, &ctx->evk1})
+        if ((e = hipEventCreate(ev)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = ctx->d_counters.reserve(sizeof(DCounters))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = ctx->d_next_count.reserve(sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
+    // per-lane BVH stacks may need more than the default 64 KiB of LDS per workgroup
+    for (const void *k : {(const void *)k_paths<false>, (const void *)k_paths<true>, (const void *)k_trace,
+                          (const void *)k_trace_shadow, (const void *)k_trace_paths})
+        (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    *out = ctx;
+    return RT_OK;
+}
+
+void rt_shutdown(rt_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
+    for (hipEvent_t ev : {ctx->ev0, ctx->ev1, ctx->evk0, ctx->evk1}) if (ev) (void)hipEventDestroy(ev);
+    delete ctx;
+}
+
+int rt_set_counting(rt_ctx *ctx, int on)
+{
+    if (!ctx) return RT_ERR_INVALID;
+    ctx->counting = on != 0;
+    return RT_OK;
+}
+
+int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc)
+{
+    if (!ctx) return RT_ERR_INVALID;
+    if (!sc || !sc->nodes || sc->n_nodes == 0) return ctx->fail(RT_ERR_INVALID, "scene has no nodes");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->have_scene = false;
+
+    // ---- validate: the kernels index with what is checked here ----
+    const uint32_t nn = sc->n_nodes;
+    std::vector<DNode> nodes(nn);
+    int max_mesh_depth = -1;
+    for (uint32_t i = 0; i < nn; ++i) {
+        const rt_node &n = sc->nodes[i];
+        if ((i == 0 && n.parent != -1) || (i > 0 && (n.parent < 0 || n.parent >= (int)i)))
+            return ctx->fail(RT_ERR_INVALID, "node %u: nodes must be in depth-first order with parent < index", i);
+        DNode &d = nodes[i];
+        memset(&d, 0, sizeof d);
+        memcpy(d.itm, n.itm, sizeof d.itm); memcpy(d.tm, n.tm, sizeof d.tm);
+        d.parent = n.parent; d.prim = n.prim; d.mesh = n.mesh; d.material = n.material;
+        d.depth = i == 0 ? 0 : nodes[n.parent].depth + 1;
+        if (d.depth >= kMaxSceneDepth)
+            return ctx->fail(RT_ERR_UNSUPPORTED, "node %u: hierarchy deeper than %d levels", i, kMaxSceneDepth);
+        if (i > 0) {
+            // depth-first order: the parent must be the previous node or one of its ancestors
+            int a = (int)i - 1;
+            while (a >= 0 && a != n.parent) a = nodes[a].parent;
+            if (a != n.parent) return ctx->fail(RT_ERR_INVALID, "node %u: not in depth-first order", i);
+            nodes[n.parent].has_children = 1;
+            memcpy(d.chain, nodes[n.parent].chain, sizeof d.chain);
+        }
+        d.chain[d.depth] = (int)i;
+        if (n.prim < RT_PRIM_NONE || n.prim > RT_PRIM_MESH) return ctx->fail(RT_ERR_INVALID, "node %u: unknown primitive %d", i, n.prim);
+        if (n.prim != RT_PRIM_NONE) {
+            // the reference casts the node's material unchecked (src/main.cpp:212): a
+            // missing one is undefined there and refused here
+            if (n.material < 0 || n.material >= (int)sc->n_materials)
+                return ctx->fail(RT_ERR_UNSUPPORTED, "node %u: object node without a valid material", i);
+        }
+        if (n.prim == RT_PRIM_MESH) {
+            if (n.mesh < 0 || n.mesh >= (int)sc->n_meshes) return ctx->fail(RT_ERR_INVALID, "node %u: mesh index out of range", i);
+        }
+    }
+    if (sc->n_lights < 1 || !sc->lights || sc->lights[0].type != RT_LIGHT_POINT || !(sc->lights[0].size > 0.0f))
+        return ctx->fail(RT_ERR_UNSUPPORTED, "the path integrator needs lights[0] to be a point light with size > 0 (src/main.cpp:165)");
+
+    // ---- meshes ----
+    std::vector<DMesh> dmeshes(sc->n_meshes);
+    std::vector<std::unique_ptr<DeviceBuf>> bufs;
+    auto upload = [&](const void *src, size_t bytes, const void **dst) -> hipError_t {
+        auto b = std::make_unique<DeviceBuf>();
+        hipError_t e = b->reserve(bytes);
+        if (e != hipSuccess) return e;
+        if (bytes) e = hipMemcpy(b->p, src, bytes, hipMemcpyHostToDevice);
+        *dst = b->p;
+        bufs.push_back(std::move(b));
+        return e;
+    };
+    for (uint32_t mi = 0; mi < sc->n_meshes; ++mi) {
+        const rt_mesh &m = sc->meshes[mi];
+        if (!m.v || !m.vn || !m.vt || !m.f || !m.fn || !m.ft || !m.bvh_nodes || !m.bvh_elements || m.nf == 0 || m.n_bvh_nodes < 2)
+            return ctx->fail(RT_ERR_INVALID, "mesh %u: missing arrays (positions, normals, tex coords, faces and BVH are all required)", mi);
+        for (size_t k = 0; k < (size_t)m.nf * 3; ++k)
+            if (m.f[k] >= m.nv || m.fn[k] >= m.nvn || m.ft[k] >= m.nvt) return ctx->fail(RT_ERR_INVALID, "mesh %u: face index out of range", mi);
+        // BVH: walk it once - checks indices, finds the depth, proves it is a tree
+        std::vector<float4> bvh((size_t)m.n_bvh_nodes * 2);
+        std::vector<float4> tris((size_t)m.nf * 3);
+        std::vector<uint8_t> seen(m.nf, 0);
+        uint32_t depth = 0;
+        size_t visited = 0;
+        std::vector<std::pair<uint32_t, uint32_t>> stack{{1u, 0u}};
+        while (!stack.empty()) {
+            auto [id, lvl] = stack.back();
+            stack.pop_back();
+            if (id == 0 || id >= m.n_bvh_nodes || ++visited > m.n_bvh_nodes) return ctx->fail(RT_ERR_INVALID, "mesh %u: BVH node index out of range or cyclic", mi);
+            depth = std::max(depth, lvl);
+            const rt_bvh_node &b = m.bvh_nodes[id];
+            bvh[id * 2] = make_float4(b.bounds[0], b.bounds[1], b.bounds[2], b.bounds[3]);
+            bvh[id * 2 + 1] = make_float4(b.bounds[4], b.bounds[5], __builtin_bit_cast(float, b.data), 0.0f);
+            if (b.data & 0x80000000u) {
+                const uint32_t off = b.data & 0x0FFFFFFFu, cnt = ((b.data >> 28) & 7u) + 1;
+                if ((size_t)off + cnt > m.nf) return ctx->fail(RT_ERR_INVALID, "mesh %u: BVH leaf out of range", mi);
+                for (uint32_t k = off; k < off + cnt; ++k) {
+                    const uint32_t face = m.bvh_elements[k];
+                    if (face >= m.nf) return ctx->fail(RT_ERR_INVALID, "mesh %u: BVH element out of range", mi);
+                    seen[k] = 1;
+                    const float *v0 = &m.v[m.f[face * 3] * 3], *v1 = &m.v[m.f[face * 3 + 1] * 3], *v2 = &m.v[m.f[face * 3 + 2] * 3];
+                    tris[(size_t)k * 3] = make_float4(v0[0], v0[1], v0[2], v1[0]);
+                    tris[(size_t)k * 3 + 1] = make_float4(v1[1], v1[2], v2[0], v2[1]);
+                    tris[(size_t)k * 3 + 2] = make_float4(v2[2], __builtin_bit_cast(float, face), 0.0f, 0.0f);
+                }
+            } else {
+                const uint32_t c = b.data & 0x7FFFFFFFu;
+                if (c & 1u) return ctx->fail(RT_ERR_UNSUPPORTED, "mesh %u: BVH child pairs must start at even indices", mi);
+                stack.push_back({c, lvl + 1});
+                stack.push_back({c + 1, lvl + 1});
+            }
+        }
+        max_mesh_depth = std::max(max_mesh_depth, (int)depth);
+        DMesh &d = dmeshes[mi];
+        d.n_nodes = m.n_bvh_nodes; d.depth = depth;
+        HIP_TRY(ctx, upload(bvh.data(), bvh.size() * sizeof(float4), (const void **)&d.bvh));
+        HIP_TRY(ctx, upload(tris.data(), tris.size() * sizeof(float4), (const void **)&d.tris));
+        HIP_TRY(ctx, upload(m.fn, (size_t)m.nf * 12, (const void **)&d.fn));
+        HIP_TRY(ctx, upload(m.ft, (size_t)m.nf * 12, (const void **)&d.ft));
+        HIP_TRY(ctx, upload(m.vn, (size_t)m.nvn * 12, (const void **)&d.vn));
+        HIP_TRY(ctx, upload(m.vt, (size_t)m.nvt * 12, (const void **)&d.vt));
+    }
+    DScene S{};
+    S.stack_levels = max_mesh_depth < 0 ? 0 : max_mesh_depth + 2;
+    if (stack_lds_bytes(S) > 160 * 1024)
+        return ctx->fail(RT_ERR_UNSUPPORTED, "BVH depth %d needs more LDS stack than a workgroup has", max_mesh_depth);
+
+    HIP_TRY(ctx, ctx->d_nodes.reserve(sizeof(DNode) * nn));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_nodes.p, nodes.data(), sizeof(DNode) * nn, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, ctx->d_meshes.reserve(sizeof(DMesh) * std::max<size_t>(1, dmeshes.size())));
+    if (!dmeshes.empty()) HIP_TRY(ctx, hipMemcpy(ctx->d_meshes.p, dmeshes.data(), sizeof(DMesh) * dmeshes.size(), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, ctx->d_materials.reserve(sizeof(rt_material) * std::max<uint32_t>(1, sc->n_materials)));
+    if (sc->n_materials) HIP_TRY(ctx, hipMemcpy(ctx->d_materials.p, sc->materials, sizeof(rt_material) * sc->n_materials, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, ctx->d_lights.reserve(sizeof(rt_light) * sc->n_lights));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_lights.p, sc->lights, sizeof(rt_light) * sc->n_lights, hipMemcpyHostToDevice));
+
+    S.nodes = ctx->d_nodes.as<DNode>();
+    S.meshes = ctx->d_meshes.as<DMesh>();
+    S.materials = ctx->d_materials.as<rt_material>();
+    S.lights = ctx->d_lights.as<rt_light>();
+    S.n_nodes = (int)nn; S.n_lights = (int)sc->n_lights;
+    memcpy(S.background, sc->background, 12);
+    ctx->mesh_bufs.swap(bufs);
+    ctx->scene = S;
+    ctx->have_scene = true;
+    return RT_OK;
+}
+
+int rt_camera_set(rt_ctx *ctx, const rt_camera *cam)
+{
+    if (!ctx) return RT_ERR_INVALID;
+    if (!cam) return ctx->fail(RT_ERR_INVALID, "null camera");
+    if (cam->width < 1 || cam->height < 1 || (int64_t)cam->width * cam->height > (int64_t)1 << 28)
+        return ctx->fail(RT_ERR_INVALID, "image size %dx%d out of range", cam->width, cam->height);
+    ctx->camera = *cam;
+    ctx->have_camera = true;
+    return RT_OK;
+}
+
+int rt_get_counters(rt_ctx *ctx, rt_counters *out)
+{
+    if (!ctx || !out) return RT_ERR_INVALID;
+    *out = ctx->counters;
+    return RT_OK;
+}
+
+int rt_render(rt_ctx *ctx, const rt_render_params *prm, rt_frame_out *out)
+{
+    if (!ctx) return RT_ERR_INVALID;
+    if (!ctx->have_scene || !ctx->have_camera) return ctx->fail(RT_ERR_STATE, "rt_render needs rt_scene_upload and rt_camera_set first");
+    if (!out) return ctx->fail(RT_ERR_INVALID, "null frame output");
+    if (int rc = validate_params(ctx, prm)) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const int W = ctx->camera.width, H = ctx->camera.height;
+    const size_t npx = (size_t)W * H;
+
+    DFrame F;
+    fill_frame(ctx, prm, F);
+
+    // halton tables (src/main.cpp:109-112): bases 2,3,5,7, `period` entries each
+    float hal[256] = {0};
+    const int bases[4] = {2, 3, 5, 7};
+    for (int b = 0; b < 4; ++b) for (int i = 0; i < prm->halton_period; ++i) hal[b * 64 + i] = halton(i, bases[b]);
+    HIP_TRY(ctx, ctx->d_halton.reserve(sizeof hal));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_halton.p, hal, sizeof hal, hipMemcpyHostToDevice, s));
+
+    // pixel list of this shard in tile order (src/main.cpp:278-288), cached per image/tile geometry
+    const int key[5] = {W, H, prm->tile_size, prm->tile_rank, prm->tile_world};
+    if (memcmp(key, ctx->active_key, sizeof key) != 0) {
+        const int ts = prm->tile_size;
+        const int tx = (W + ts - 1) / ts, ty = (H + ts - 1) / ts;
+        ctx->active_host.clear();
+        for (int t = prm->tile_rank; t < tx * ty; t += prm->tile_world) {
+            const int x0 = (t % tx) * ts, y0 = (t / tx) * ts;
+            const int tw = std::min(ts, W - x0), th = std::min(ts, H - y0);
+            for (int j = y0; j < y0 + th; ++j) for (int i = x0; i < x0 + tw; ++i) ctx->active_host.push_back(j * W + i);
+        }
+        memcpy(ctx->active_key, key, sizeof key);
+    }
+    const uint32_t n0 = (uint32_t)ctx->active_host.size();
+    for (auto &b : ctx->d_active) HIP_TRY(ctx, b.reserve(sizeof(int32_t) * std::max<uint32_t>(1, n0)));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_active[0].p, ctx->active_host.data(), sizeof(int32_t) * n0, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, ctx->d_state.reserve(sizeof(PixelState) * npx));
+
+    // output planes: the caller's device memory, or internal planes copied out afterwards
+    FramePlanes P{};
+    const bool dev_out = out->device_memory != 0;
+    if (dev_out) {
+        P.rgb = out->rgb; P.z = out->z; P.sample_count = out->sample_count; P.object_id = out->object_id; P.linear = out->linear;
+    } else {
+        if (out->rgb) { HIP_TRY(ctx, ctx->d_rgb.reserve(npx * 3)); P.rgb = ctx->d_rgb.as<uint8_t>(); }
+        if (out->z) { HIP_TRY(ctx, ctx->d_z.reserve(npx * 4)); P.z = ctx->d_z.as<float>(); }
+        if (out->sample_count) { HIP_TRY(ctx, ctx->d_cnt.reserve(npx * 4)); P.sample_count = ctx->d_cnt.as<int32_t>(); }
+        if (out->object_id) { HIP_TRY(ctx, ctx->d_id.reserve(npx * 4)); P.object_id = ctx->d_id.as<int32_t>(); }
+        if (out->linear) { HIP_TRY(ctx, ctx->d_lin.reserve(npx * 12)); P.linear = ctx->d_lin.as<float>(); }
+    }
+
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters.p, 0, sizeof(DCounters), s));
+    const size_t lds = stack_lds_bytes(ctx->scene);
+    double trace_ms = 0.0;
+    uint32_t launches = 0;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev0, s));
+
+    // sampling rounds: the first takes min_spp samples of every pixel, later ones
+    // up to 16 more of the pixels the stop test has not released yet
+    const uint64_t kMaxItems = 1ull << 28; // bounds the sample buffer to 4 GiB
+    uint32_t n_active = n0;
+    int cur = 0, k0 = 0;
+    while (n_active > 0 && k0 < prm->max_spp) {
+        const int nk = k0 == 0 ? prm->min_spp : std::min(16, prm->max_spp - k0);
+        const uint32_t chunk_px = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_active, kMaxItems / (uint64_t)nk));
+        HIP_TRY(ctx, ctx->d_sbuf.reserve((size_t)chunk_px * nk * sizeof(float4)));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_next_count.p, 0, sizeof(uint32_t), s));
+        for (uint32_t first = 0; first < n_active; first += chunk_px) {
+            const uint32_t cnt = std::min(chunk_px, n_active - first);
+            const uint64_t items = (uint64_t)cnt * nk;
+            const dim3 grid((unsigned)((items + kBlock - 1) / kBlock));
+            const int32_t *act = ctx->d_active[cur].as<int32_t>() + first;
+            HIP_TRY(ctx, hipEventRecord(ctx->evk0, s));
+            if (ctx->counting)
+                hipLaunchKernelGGL(k_paths<true>, grid, dim3(kBlock), lds, s, ctx->scene, F, ctx->d_halton.as<float>(), act, items,
+                                   k0, nk, ctx->d_sbuf.as<float4>(), P, ctx->d_counters.as<DCounters>());
+            else
+                hipLaunchKernelGGL(k_paths<false>, grid, dim3(kBlock), lds, s, ctx->scene, F, ctx->d_halton.as<float>(), act, items,
+                                   k0, nk, ctx->d_sbuf.as<float4>(), P, ctx->d_counters.as<DCounters>());
+            HIP_TRY(ctx, hipGetLastError());
+            HIP_TRY(ctx, hipEventRecord(ctx->evk1, s));
+            hipLaunchKernelGGL(k_resolve, dim3((cnt + kBlock - 1) / kBlock), dim3(kBlock), 0, s, F, act, cnt, k0, nk,
+                               ctx->d_sbuf.as<float4>(), ctx->d_state.as<PixelState>(), P,
+                               ctx->d_active[cur ^ 1].as<int32_t>(), ctx->d_next_count.as<uint32_t>());
+            HIP_TRY(ctx, hipGetLastError());
+            HIP_TRY(ctx, hipEventSynchronize(ctx->evk1));
+            float ms = 0;
+            HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->evk0, ctx->evk1));
+            trace_ms += ms;
+            ++launches;
+        }
+        uint32_t next = 0;
+        HIP_TRY(ctx, hipMemcpyAsync(&next, ctx->d_next_count.p, sizeof next, hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipStreamSynchronize(s));
+        n_active = next;
+        cur ^= 1;
+        k0 += nk;
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->ev1, s));
+
+    DCounters dc{};
+    HIP_TRY(ctx, hipMemcpyAsync(&dc, ctx->d_counters.p, sizeof dc, hipMemcpyDeviceToHost, s));
+    if (!dev_out) {
+        // whole image: straight copies; a tile shard: stage and copy only the rows of its tiles
+        const bool whole = prm->tile_world == 1;
+        struct Plane { void *dst; const DeviceBuf *src; size_t px_bytes; };
+        const Plane planes[5] = {{out->rgb, &ctx->d_rgb, 3}, {out->z, &ctx->d_z, 4}, {out->sample_count, &ctx->d_cnt, 4},
+                                 {out->object_id, &ctx->d_id, 4}, {out->linear, &ctx->d_lin, 12}};
+        std::vector<uint8_t> stage;
+        for (const Plane &pl : planes) {
+            if (!pl.dst) continue;
+            if (whole) { HIP_TRY(ctx, hipMemcpyAsync(pl.dst, pl.src->p, npx * pl.px_bytes, hipMemcpyDeviceToHost, s)); continue; }
+            stage.resize(npx * pl.px_bytes);
+            HIP_TRY(ctx, hipMemcpyAsync(stage.data(), pl.src->p, npx * pl.px_bytes, hipMemcpyDeviceToHost, s));
+            HIP_TRY(ctx, hipStreamSynchronize(s));
+            for (int32_t pix : ctx->active_host)
+                memcpy((uint8_t *)pl.dst + (size_t)pix * pl.px_bytes, stage.data() + (size_t)pix * pl.px_bytes, pl.px_bytes);
+        }
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    float ms = 0;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    rt_counters &c = ctx->counters;
+    c.closest_rays = dc.closest; c.shadow_rays = dc.shadow; c.camera_paths = dc.paths;
+    c.box_tests = dc.box_tests; c.tri_tests = dc.tri_tests;
+    c.kernel_ms = ms; c.trace_kernel_ms = trace_ms; c.trace_launches = launches;
+    return RT_OK;
+}
+
+// ---- batch queries ----
+static int batch_common(rt_ctx *ctx, const float *rays6, int n)
+{
+    if (!ctx) return RT_ERR_INVALID;
+    if (!ctx->have_scene) return ctx->fail(RT_ERR_STATE, "no scene uploaded");
+    if (n < 0 || (n > 0 && !rays6)) return ctx->fail(RT_ERR_INVALID, "bad ray array");
+    return RT_OK;
+}
+
+int rt_trace(rt_ctx *ctx, const float *rays6, int n, rt_hit *out)
+{
+    if (int rc = batch_common(ctx, rays6, n)) return rc;
+    if (n == 0) return RT_OK;
+    if (!out) return ctx->fail(RT_ERR_INVALID, "null output");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    HIP_TRY(ctx, ctx->d_q_in.reserve((size_t)n * 24));
+    HIP_TRY(ctx, ctx->d_q_out.reserve((size_t)n * sizeof(rt_hit)));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_q_in.p, rays6, (size_t)n * 24, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_trace, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), stack_lds_bytes(ctx->scene), s, ctx->scene,
+                       ctx->d_q_in.as<float>(), n, ctx->d_q_out.as<rt_hit>());
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(out, ctx->d_q_out.p, (size_t)n * sizeof(rt_hit), hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    return RT_OK;
+}
+
+int rt_trace_shadow(rt_ctx *ctx, const float *rays6, const float *t_max, int n, int32_t *occluded)
+{
+    if (int rc = batch_common(ctx, rays6, n)) return rc;
+    if (n == 0) return RT_OK;
+    if (!t_max || !occluded) return ctx->fail(RT_ERR_INVALID, "null argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    HIP_TRY(ctx, ctx->d_q_in.reserve((size_t)n * 24));
+    HIP_TRY(ctx, ctx->d_q_aux.reserve((size_t)n * 4));
+    HIP_TRY(ctx, ctx->d_q_out.reserve((size_t)n * 4));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_q_in.p, rays6, (size_t)n * 24, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_q_aux.p, t_max, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_trace_shadow, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), stack_lds_bytes(ctx->scene), s, ctx->scene,
+                       ctx->d_q_in.as<float>(), ctx->d_q_aux.as<float>(), n, ctx->d_q_out.as<int32_t>());
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(occluded, ctx->d_q_out.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    return RT_OK;
+}
+
+int rt_trace_paths(rt_ctx *ctx, const float *rays6, int n, uint64_t seed, const rt_render_params *prm, float *radiance3)
+{
+    if (int rc = batch_common(ctx, rays6, n)) return rc;
+    if (int rc = validate_params(ctx, prm)) return rc;
+    if (n == 0) return RT_OK;
+    if (!radiance3) return ctx->fail(RT_ERR_INVALID, "null output");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    DFrame F;
+    memset(&F, 0, sizeof F);
+    F.max_bounces = prm->max_bounces; F.bias = prm->bias; F.seed = seed;
+    HIP_TRY(ctx, ctx->d_q_in.reserve((size_t)n * 24));
+    HIP_TRY(ctx, ctx->d_q_out.reserve((size_t)n * 12));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_q_in.p, rays6, (size_t)n * 24, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters.p, 0, sizeof(DCounters), s));
+    hipLaunchKernelGGL(k_trace_paths, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), stack_lds_bytes(ctx->scene), s, ctx->scene, F,
+                       ctx->d_q_in.as<float>(), n, ctx->d_q_out.as<float>(), ctx->d_counters.as<DCounters>());
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(radiance3, ctx->d_q_out.p, (size_t)n * 12, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    return RT_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,226 @@
+"""ctypes binding of ``librt_mi355x.so`` - plumbing only, no arithmetic.
+
+The shared library is built in-tree by ``__graft_entry__.build()`` (or
+``make -C raytracer_amd/csrc``).  Loading fails loudly when it is missing:
+there is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librt_mi355x.so")
+
+# every symbol include/rt_mi355x.h declares
+SYMBOLS = (
+    "rt_abi_version", "rt_init", "rt_shutdown", "rt_last_error", "rt_scene_upload", "rt_camera_set", "rt_render",
+    "rt_trace", "rt_trace_shadow", "rt_trace_paths", "rt_get_counters", "rt_set_counting",
+    "rt_scene_load_xml", "rt_scene_from_xml_string", "rt_scene_host_desc", "rt_scene_host_camera",
+    "rt_scene_host_free", "rt_scene_host_set_mesh", "rt_bvh_build", "rt_free",
+)
+
+_lib = None
+
+
+class RtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"rt error {code}: {msg}")
+        self.code = code
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing - build it with `python -c 'import __graft_entry__ as g; g.build()'`")
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.rt_abi_version.restype = C.c_int
+    L.rt_init.argtypes = [C.c_int, C.POINTER(vp)]
+    L.rt_shutdown.argtypes = [vp]
+    L.rt_shutdown.restype = None
+    L.rt_last_error.argtypes = [vp]
+    L.rt_last_error.restype = C.c_char_p
+    L.rt_scene_upload.argtypes = [vp, C.POINTER(abi.SceneDesc)]
+    L.rt_camera_set.argtypes = [vp, C.POINTER(abi.Camera)]
+    L.rt_render.argtypes = [vp, C.POINTER(abi.RenderParams), C.POINTER(abi.FrameOut)]
+    L.rt_trace.argtypes = [vp, abi.f32p, C.c_int, C.POINTER(abi.Hit)]
+    L.rt_trace_shadow.argtypes = [vp, abi.f32p, abi.f32p, C.c_int, abi.i32p]
+    L.rt_trace_paths.argtypes = [vp, abi.f32p, C.c_int, C.c_uint64, C.POINTER(abi.RenderParams), abi.f32p]
+    L.rt_get_counters.argtypes = [vp, C.POINTER(abi.Counters)]
+    L.rt_set_counting.argtypes = [vp, C.c_int]
+    L.rt_scene_load_xml.argtypes = [C.c_char_p, C.POINTER(vp), C.c_char_p, C.c_size_t]
+    L.rt_scene_from_xml_string.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(vp), C.c_char_p, C.c_size_t]
+    L.rt_scene_host_desc.argtypes = [vp]
+    L.rt_scene_host_desc.restype = C.POINTER(abi.SceneDesc)
+    L.rt_scene_host_camera.argtypes = [vp]
+    L.rt_scene_host_camera.restype = C.POINTER(abi.Camera)
+    L.rt_scene_host_free.argtypes = [vp]
+    L.rt_scene_host_free.restype = None
+    L.rt_scene_host_set_mesh.argtypes = [vp, C.c_char_p, abi.f32p, abi.f32p, C.c_uint32, abi.u32p, C.c_uint32,
+                                         C.c_char_p, C.c_size_t]
+    L.rt_bvh_build.argtypes = [abi.f32p, C.c_uint32, abi.u32p, C.c_uint32, C.c_uint32,
+                               C.POINTER(C.POINTER(abi.BvhNode)), C.POINTER(C.c_uint32),
+                               C.POINTER(abi.u32p), C.POINTER(C.c_uint32)]
+    L.rt_free.argtypes = [vp]
+    L.rt_free.restype = None
+    _lib = L
+    return L
+
+
+class HostScene:
+    """A scene read by the library's own scene.xml reader (host memory, no GPU needed)."""
+
+    def __init__(self, handle):
+        self._h = handle
+        self.desc = load().rt_scene_host_desc(handle).contents
+        self.camera = load().rt_scene_host_camera(handle).contents
+
+    @classmethod
+    def from_file(cls, path):
+        h, err = C.c_void_p(), C.create_string_buffer(512)
+        rc = load().rt_scene_load_xml(os.fsencode(path), C.byref(h), err, len(err))
+        if rc:
+            raise RtError(rc, err.value.decode())
+        return cls(h)
+
+    @classmethod
+    def from_string(cls, xml, base_dir=""):
+        h, err = C.c_void_p(), C.create_string_buffer(512)
+        rc = load().rt_scene_from_xml_string(xml.encode(), os.fsencode(base_dir), C.byref(h), err, len(err))
+        if rc:
+            raise RtError(rc, err.value.decode())
+        return cls(h)
+
+    def set_mesh(self, node_name, v, vt, f):
+        v = np.ascontiguousarray(v, np.float32)
+        vt = np.ascontiguousarray(vt, np.float32)
+        f = np.ascontiguousarray(f, np.uint32)
+        err = C.create_string_buffer(512)
+        rc = load().rt_scene_host_set_mesh(self._h, node_name.encode(), v.ctypes.data_as(abi.f32p),
+                                           vt.ctypes.data_as(abi.f32p), len(v), f.ctypes.data_as(abi.u32p), len(f),
+                                           err, len(err))
+        if rc:
+            raise RtError(rc, err.value.decode())
+        self.desc = load().rt_scene_host_desc(self._h).contents
+
+    def close(self):
+        if self._h:
+            load().rt_scene_host_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+def bvh_build(v, f, max_leaf=4):
+    v = np.ascontiguousarray(v, np.float32)
+    f = np.ascontiguousarray(f, np.uint32)
+    nodes, elems = C.POINTER(abi.BvhNode)(), abi.u32p()
+    nn, depth = C.c_uint32(), C.c_uint32()
+    rc = load().rt_bvh_build(v.ctypes.data_as(abi.f32p), len(v), f.ctypes.data_as(abi.u32p), len(f), max_leaf,
+                             C.byref(nodes), C.byref(nn), C.byref(elems), C.byref(depth))
+    if rc:
+        raise RtError(rc, "rt_bvh_build failed")
+    try:
+        words = np.ctypeslib.as_array(C.cast(nodes, abi.u32p), shape=(nn.value, 7)).copy()
+        el = np.ctypeslib.as_array(elems, shape=(len(f),)).copy()
+    finally:
+        load().rt_free(nodes)
+        load().rt_free(elems)
+    return words, el, depth.value
+
+
+class Frame:
+    """Host output planes of one frame."""
+
+    def __init__(self, w, h):
+        self.rgb = np.zeros((h, w, 3), np.uint8)
+        self.z = np.zeros((h, w), np.float32)
+        self.sample_count = np.zeros((h, w), np.int32)
+        self.object_id = np.full((h, w), -9, np.int32)
+        self.linear = np.zeros((h, w, 3), np.float32)
+        self.out = abi.FrameOut(self.rgb.ctypes.data, self.z.ctypes.data, self.sample_count.ctypes.data,
+                                self.object_id.ctypes.data, self.linear.ctypes.data, 0)
+
+
+class Context:
+    """One GPU.  Mirrors the call order of the reference's Renderer: load scene, render, read images."""
+
+    def __init__(self, device=0):
+        self._L = load()
+        self._h = C.c_void_p()
+        rc = self._L.rt_init(device, C.byref(self._h))
+        if rc:
+            raise RtError(rc, self._L.rt_last_error(None).decode())
+
+    def _check(self, rc):
+        if rc:
+            raise RtError(rc, self._L.rt_last_error(self._h).decode())
+
+    def upload(self, desc, camera=None):
+        self._check(self._L.rt_scene_upload(self._h, C.byref(desc)))
+        if camera is not None:
+            self.set_camera(camera)
+
+    def set_camera(self, camera, width=None, height=None):
+        cam = abi.Camera.from_buffer_copy(camera)
+        if width:
+            cam.width, cam.height = width, height
+        self._check(self._L.rt_camera_set(self._h, C.byref(cam)))
+        self.width, self.height = cam.width, cam.height
+
+    def set_counting(self, on):
+        self._check(self._L.rt_set_counting(self._h, int(on)))
+
+    def render(self, params, frame=None):
+        fr = frame or Frame(self.width, self.height)
+        self._check(self._L.rt_render(self._h, C.byref(params), C.byref(fr.out)))
+        return fr
+
+    def render_device(self, params, rgb=0, z=0, sample_count=0, object_id=0, linear=0):
+        """Render into device memory; arguments are device addresses (0 = plane not wanted)."""
+        out = abi.FrameOut(rgb or None, z or None, sample_count or None, object_id or None, linear or None, 1)
+        self._check(self._L.rt_render(self._h, C.byref(params), C.byref(out)))
+
+    def counters(self):
+        c = abi.Counters()
+        self._check(self._L.rt_get_counters(self._h, C.byref(c)))
+        return c
+
+    def trace(self, rays):
+        rays = np.ascontiguousarray(rays, np.float32)
+        hits = np.zeros(len(rays), abi.HIT_DTYPE)
+        self._check(self._L.rt_trace(self._h, rays.ctypes.data_as(abi.f32p), len(rays),
+                                     C.cast(hits.ctypes.data, C.POINTER(abi.Hit))))
+        return hits
+
+    def trace_shadow(self, rays, tmax):
+        rays = np.ascontiguousarray(rays, np.float32)
+        tmax = np.ascontiguousarray(tmax, np.float32)
+        out = np.zeros(len(rays), np.int32)
+        self._check(self._L.rt_trace_shadow(self._h, rays.ctypes.data_as(abi.f32p), tmax.ctypes.data_as(abi.f32p),
+                                            len(rays), out.ctypes.data_as(abi.i32p)))
+        return out
+
+    def trace_paths(self, rays, seed, params):
+        rays = np.ascontiguousarray(rays, np.float32)
+        out = np.zeros((len(rays), 3), np.float32)
+        self._check(self._L.rt_trace_paths(self._h, rays.ctypes.data_as(abi.f32p), len(rays), seed, C.byref(params),
+                                           out.ctypes.data_as(abi.f32p)))
+        return out
+
+    def close(self):
+        if self._h:
+            self._L.rt_shutdown(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,164 @@
+"""Host side of the C ABI (no GPU): the library loads and exports what the header
+declares, and its scene.xml / OBJ readers and BVH builder produce the very
+arrays the reference's loader produced for the same text (golden fixtures hold
+the reference's dump next to the scene text it was given)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oraclelib as O
+from raytracer_amd import abi, lib, scenes
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def test_library_exports_every_declared_symbol():
+    L = lib.load()
+    header = open(os.path.join(ROOT, "include", "rt_mi355x.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(lib.SYMBOLS)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.rt_abi_version() == 1
+
+
+def test_struct_sizes_match_header():
+    assert C.sizeof(abi.Node) == 112
+    assert C.sizeof(abi.BvhNode) == 28
+    assert C.sizeof(abi.Material) == 80
+    assert C.sizeof(abi.Light) == 48
+    assert C.sizeof(abi.Hit) == 48
+    assert C.sizeof(abi.RenderParams) == 48
+
+
+def nodes_of(desc):
+    n = desc.n_nodes
+    tm = np.array([list(desc.nodes[i].tm) for i in range(n)], np.float32)
+    itm = np.array([list(desc.nodes[i].itm) for i in range(n)], np.float32)
+    meta = np.array([[desc.nodes[i].parent, desc.nodes[i].prim, desc.nodes[i].mesh, desc.nodes[i].material]
+                     for i in range(n)], np.int32)
+    return tm, itm, meta
+
+
+def check_scene_against_dump(hs, g):
+    d = hs.desc
+    tm, itm, meta = nodes_of(d)
+    assert d.n_nodes == len(g["scene_node_parent"])
+    assert np.array_equal(meta[:, 0], g["scene_node_parent"])
+    assert np.array_equal(meta[:, 1], g["scene_node_prim"])
+    assert np.array_equal(meta[:, 2], g["scene_node_mesh"])
+    assert np.array_equal(meta[:, 3], g["scene_node_material"])
+    assert np.array_equal(bits(tm), bits(g["scene_node_tm"])), "node transforms"
+    assert np.array_equal(bits(itm), bits(g["scene_node_itm"])), "inverse node transforms"
+    mats = np.array([list(m.diffuse) + list(m.specular) + [m.glossiness] + list(m.emission) + list(m.reflection) +
+                     list(m.refraction) + list(m.absorption) + [m.ior]
+                     for m in (d.materials[i] for i in range(d.n_materials))], np.float32)
+    assert np.array_equal(bits(mats), bits(g["scene_materials"]))
+    lights = np.array([[l.type] + list(l.intensity) + list(l.position) + list(l.direction) + [l.size, l.attenuation]
+                       for l in (d.lights[i] for i in range(d.n_lights))], np.float32)
+    assert np.array_equal(bits(lights), bits(g["scene_lights"]))
+    c = hs.camera
+    cam = np.array(list(c.pos) + list(c.dir) + list(c.up) + [c.fov, c.focaldist, c.dof, c.width, c.height, c.srgb], np.float32)
+    assert np.array_equal(bits(cam), bits(g["scene_camera"]))
+    assert np.array_equal(bits(list(d.background)), bits(g["scene_background"]))
+
+
+@pytest.mark.parametrize("name", ["image_nested_96x54_s8", "image_spheres_96x54_s8"])
+def test_xml_reader_matches_reference_loader(name):
+    g = O.load_golden(name)
+    hs = lib.HostScene.from_string(bytes(g["xml"]).decode())
+    check_scene_against_dump(hs, g)
+
+
+def mesh_arrays(m):
+    A = np.ctypeslib.as_array
+    return dict(v=A(m.v, (m.nv, 3)), vn=A(m.vn, (m.nvn, 3)), vt=A(m.vt, (m.nvt, 3)),
+                f=A(m.f, (m.nf, 3)), fn=A(m.fn, (m.nf, 3)), ft=A(m.ft, (m.nf, 3)),
+                bvh_nodes=A(C.cast(m.bvh_nodes, abi.u32p), (m.n_bvh_nodes, 7)), bvh_elements=A(m.bvh_elements, (m.nf,)))
+
+
+def check_mesh(m, g):
+    a = mesh_arrays(m)
+    for k in ("v", "vn", "vt"):
+        assert np.array_equal(bits(a[k]), bits(g["scene_mesh0_" + k])), k
+    for k in ("f", "fn", "ft", "bvh_elements"):
+        assert np.array_equal(a[k], g["scene_mesh0_" + k]), k
+    ref = g["scene_mesh0_bvh_nodes"]
+    assert a["bvh_nodes"].shape == ref.shape
+    assert np.array_equal(a["bvh_nodes"][1:], ref[1:]), "BVH nodes"
+    assert m.bvh_depth == abi.bvh_depth(ref)
+
+
+def test_mesh_scene_from_obj_file(tmp_path):
+    g = O.load_golden("scene_mesh")
+    mesh = scenes.heightfield(nx=int(g["mesh_nx"]), ny=int(g["mesh_ny"]))
+    scenes.write_obj(tmp_path / "mesh_small.obj", mesh)
+    (tmp_path / "scene.xml").write_bytes(bytes(g["xml"]))
+    hs = lib.HostScene.from_file(str(tmp_path / "scene.xml"))
+    check_scene_against_dump(hs, g)
+    check_mesh(hs.desc.meshes[0], g)
+
+
+def test_mesh_scene_from_arrays():
+    g = O.load_golden("scene_mesh")
+    mesh = scenes.heightfield(nx=int(g["mesh_nx"]), ny=int(g["mesh_ny"]))
+    hs = lib.HostScene.from_string(bytes(g["xml"]).decode())
+    assert hs.desc.meshes[0].nf == 0  # file absent: mesh stays empty until set
+    hs.set_mesh("mesh_small.obj", mesh["v"], mesh["vt"], mesh["f"])
+    check_mesh(hs.desc.meshes[0], g)
+
+
+def test_bvh_build_entry_point():
+    g = O.load_golden("scene_mesh")
+    words, elems, depth = lib.bvh_build(g["scene_mesh0_v"], g["scene_mesh0_f"], 4)
+    assert np.array_equal(words[1:], g["scene_mesh0_bvh_nodes"][1:])
+    assert np.array_equal(elems, g["scene_mesh0_bvh_elements"])
+    assert depth == abi.bvh_depth(g["scene_mesh0_bvh_nodes"])
+    leaves = words[1:][(words[1:, 6] & 0x80000000) != 0]
+    assert (((leaves[:, 6] >> 28) & 7) + 1).max() <= 4
+
+
+def test_obj_reader_polygons_and_negative_indices(tmp_path):
+    (tmp_path / "quad.obj").write_text(
+        "# a quad and a pentagon, fan-triangulated\n"
+        "v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nv 2 0.5 1\n"
+        "vt 0 0 0\nvt 1 0 0\nvt 1 1 0\nvt 0 1 0\nvt 0.5 0.5 0\n"
+        "f 1/1 2/2 3/3 4/4\n"
+        "f -5/-5 -4/-4 -1/-1 -3/-3 -2/-2\n")
+    xml = scenes.mesh_scene_xml("quad.obj", 32, 18)
+    (tmp_path / "s.xml").write_text(xml)
+    hs = lib.HostScene.from_file(str(tmp_path / "s.xml"))
+    a = mesh_arrays(hs.desc.meshes[0])
+    assert a["f"].tolist() == [[0, 1, 2], [0, 2, 3], [0, 1, 4], [0, 4, 2], [0, 2, 3]]
+    assert np.array_equal(a["ft"], a["f"]) and np.array_equal(a["fn"], a["f"])
+    assert a["vn"].shape == (5, 3)
+
+
+def test_error_reporting():
+    with pytest.raises(lib.RtError) as e:
+        lib.HostScene.from_file("/nonexistent/scene.xml")
+    assert e.value.code == abi.RT_ERR_IO and "Failed to load" in str(e.value)
+    for bad, msg in [("<xml><scene></scene></xml>", "camera"), ("<xml><camera/></xml>", "scene"),
+                     ("<scene/>", "xml"), ("<xml><scene>", "missing")]:
+        with pytest.raises(lib.RtError) as e:
+            lib.HostScene.from_string(bad)
+        assert e.value.code == abi.RT_ERR_IO and msg in str(e.value)
+
+
+def test_init_without_gpu_fails_cleanly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    L = lib.load()
+    h = C.c_void_p()
+    rc = L.rt_init(0, C.byref(h))
+    assert rc == abi.RT_ERR_NO_DEVICE and not h.value
+    assert b"HIP device" in L.rt_last_error(None)
