@@ -24,9 +24,13 @@ RT_DEV V3 operator*(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
 RT_DEV V3 operator*(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
 RT_DEV V3 operator/(V3 a, float s) { return mk(a.x / s, a.y / s, a.z / s); }
 RT_DEV V3 operator-(V3 a) { return mk(-a.x, -a.y, -a.z); }
+// IEEE square root: hipcc expands llvm.sqrt.f32 to the correctly rounded sequence by
+// default (-fhip-fp32-correctly-rounded-divide-sqrt); __fsqrt_rn is NOT that, it maps
+// to the 1-ulp native instruction
+RT_DEV float fsqrt(float x) { return __builtin_sqrtf(x); }
 RT_DEV float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }          // cyVector.h:385
 RT_DEV float len2(V3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }               // cyVector.h:310
-RT_DEV float len(V3 a) { return __fsqrt_rn(len2(a)); }                              // cyVector.h:311
+RT_DEV float len(V3 a) { return fsqrt(len2(a)); }                              // cyVector.h:311
 RT_DEV V3 normalize(V3 a) { return a / len(a); }                                    // cyVector.h:306,309
 RT_DEV V3 cross(V3 a, V3 p)                                                         // cyVector.h:383
 {

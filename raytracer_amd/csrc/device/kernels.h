@@ -85,7 +85,7 @@ RT_DEV Ray camera_ray(const DFrame &F, const float *halton, int i, int j, int k,
     const float jt = frac_sum(halton[128 + hk], off[2]);
     const float jr = frac_sum(halton[192 + hk], off[3]);
     const float theta = (float)((double)(jt * 2.0f) * M_PI); // float*float, then *double (main.cpp:313)
-    const float radius = __fsqrt_rn(jr);
+    const float radius = fsqrt(jr);
     const V3 lens = mk(radius * F.dof * cosf(theta), radius * F.dof * sinf(theta), 0.0f);
     Ray r;
     r.p = cpos + m3_mul(F.cam2world, lens);
@@ -117,7 +117,13 @@ __global__ __launch_bounds__(kBlock) void k_paths(DScene S, DFrame F, const floa
         off[0] = rng_float(rng); off[1] = rng_float(rng); off[2] = rng_float(rng); off[3] = rng_float(rng);
         rng_set_sequence(rng, (uint64_t)k + 1, ps);
         const Ray ray = camera_ray(F, halton, i, j, k, off);
-        float fz; int fid;
+        float fz = FLT_MAX; int fid = -1;
+        if (k == 0 && F.max_bounces <= 0) { // no bounce loop to take the depth / id planes from
+            Hit h;
+            Tally<false> none;
+            const bool hit = trace_closest<false>(S, ray, st, h, none);
+            fz = h.z; fid = hit ? h.node : -1;
+        }
         const V3 c = trace_path<COUNT>(S, F, ray, rng, st, pt, tl, &fz, &fid);
         if (k == 0) {
             if (out.z) out.z[pix] = fz;
@@ -168,8 +174,8 @@ __global__ __launch_bounds__(kBlock) void k_resolve(DFrame F, const int32_t *__r
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
             float sigma = (s.sum_sq[ch] - ((s.sum[ch] * s.sum[ch]) / (float)s.n)) / (float)(s.n - 1);
-            sigma = __fsqrt_rn(fmaxf(0.0f, sigma));
-            const float delta = 3.0f * (sigma / __fsqrt_rn((float)s.n));
+            sigma = fsqrt(fmaxf(0.0f, sigma));
+            const float delta = 3.0f * (sigma / fsqrt((float)s.n));
             below = below && (delta < F.delta_max);
         }
         if (below) done = true;

@@ -31,10 +31,10 @@ RT_DEV void light_generate(const rt_light &l, V3 P, Rng &rng, Sample &o)
     const float dist = len(toC);
     toC = normalize(toC);
     const float sinMax = l.size / dist;
-    const float cosMax = __fsqrt_rn(1.0f - (sinMax * sinMax));
+    const float cosMax = fsqrt(1.0f - (sinMax * sinMax));
     const float r1 = rng_float(rng);
     const float cosT = 1.0f - r1 + r1 * cosMax;
-    const float sinT = __fsqrt_rn(1.0f - (cosT * cosT));
+    const float sinT = fsqrt(1.0f - (cosT * cosT));
     const float phi = 2.0f * kPi * rng_float(rng);
     const float x = sinT * cosf(phi);
     const float y = sinT * sinf(phi);
@@ -45,7 +45,7 @@ RT_DEV void light_generate(const rt_light &l, V3 P, Rng &rng, Sample &o)
     const float adj = hyp * cosT;
     const float oppSq = (hyp * hyp) - (adj * adj);
     const float inside = (l.size * l.size) - oppSq;
-    const float tOff = __fsqrt_rn(std_max(0.0f, inside));
+    const float tOff = fsqrt(std_max(0.0f, inside));
     o.dist = adj - tOff;
     o.dir = normalize((u * x + v * y) + toC * z);
     o.mult = light_radiance(l);
@@ -67,7 +67,7 @@ RT_DEV float light_pdf(const rt_light &l, V3 P, V3 dir)
     const float cosRaySq = cosRay * cosRay;
     const float cosMaxSq = 1.0f - sinMaxSq;
     if (cosRaySq >= cosMaxSq) {
-        const float cosMax = __fsqrt_rn(std_max(0.0f, cosMaxSq));
+        const float cosMax = fsqrt(std_max(0.0f, cosMaxSq));
         const float omc = sinMaxSq / (1.0f + cosMax);
         return 1.0f / (2.0f * kPi * omc);
     }
@@ -94,11 +94,11 @@ RT_DEV bool mtl_generate(const rt_material &m, const Surface &s, Rng &rng, Sampl
     const float rnd = rng_float(rng);
     if (rnd < pd) {
         o.lobe = LOBE_DIFFUSE;
-        const float r = __fsqrt_rn(rng_float(rng));
+        const float r = fsqrt(rng_float(rng));
         const float theta = 2.0f * kPi * rng_float(rng);
         const float x = r * cosf(theta);
         const float y = r * sinf(theta);
-        const float z = __fsqrt_rn(std_max(0.0f, 1.0f - x * x - y * y));
+        const float z = fsqrt(std_max(0.0f, 1.0f - x * x - y * y));
         V3 u, v;
         orthonormals(Ns, u, v);
         const V3 dir = (u * x + v * y) + Ns * z;
@@ -113,7 +113,7 @@ RT_DEV bool mtl_generate(const rt_material &m, const Surface &s, Rng &rng, Sampl
         const float alpha = m.glossiness;
         const float phi = 2.0f * kPi * rng_float(rng);
         const float cosT = powf(1.0f - rng_float(rng), 1.0f / (alpha + 1.0f));
-        const float sinT = __fsqrt_rn(1.0f - cosT * cosT);
+        const float sinT = fsqrt(1.0f - cosT * cosT);
         const float x = sinT * cosf(phi);
         const float y = sinT * sinf(phi);
         V3 u, v;
@@ -139,7 +139,7 @@ RT_DEV bool mtl_generate(const rt_material &m, const Surface &s, Rng &rng, Sampl
         const float alpha = m.glossiness;
         const float phi = 2.0f * kPi * rng_float(rng);
         const float cosT = powf(1.0f - rng_float(rng), 1.0f / (alpha + 1.0f));
-        const float sinT = __fsqrt_rn(1.0f - cosT * cosT);
+        const float sinT = fsqrt(1.0f - cosT * cosT);
         const float x = sinT * cosf(phi);
         const float y = sinT * sinf(phi);
         V3 u, v;
@@ -151,7 +151,7 @@ RT_DEV bool mtl_generate(const rt_material &m, const Surface &s, Rng &rng, Sampl
         o.prob = pt;
         const V3 refl = (h * 2.0f) * std_max(0.0f, vDotH) - V;
         if (k < 0.0f) { o.dir = refl; return true; }
-        const V3 dir = h * (eta * vDotH - __fsqrt_rn(k)) - V * eta;
+        const V3 dir = h * (eta * vDotH - fsqrt(k)) - V * eta;
         o.dir = dir;
         if (fabsf(dot(N, dir)) < 1e-5f) return false;
         const float F = fresnelRatio + (1.0f - fresnelRatio) * powf(1.0f - vDotH, 5.0f);

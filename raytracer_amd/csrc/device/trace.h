@@ -55,7 +55,7 @@ RT_DEV bool sphere_t(Ray r, float &t, int &front)
     const float c = dot(r.p, r.p) - 1.0f;
     const float disc = b * b - 4 * a * c;
     if (disc < 0.0f) return false;
-    const float s = __fsqrt_rn(disc);
+    const float s = fsqrt(disc);
     const float inv2a = 1.0f / (2.0f * a);
     const float t1 = (-b - s) * inv2a;
     const float t2 = (-b + s) * inv2a;
@@ -71,7 +71,7 @@ RT_DEV bool sphere_shadow(Ray r, float t_max)
     const float c = dot(r.p, r.p) - 1.0f;
     const float disc = b * b - 4 * a * c;
     if (disc < 0.0f) return false;
-    const float s = __fsqrt_rn(disc);
+    const float s = fsqrt(disc);
     const float inv2a = 1.0f / (2.0f * a);
     const float t1 = (-b - s) * inv2a;
     const float t2 = (-b + s) * inv2a;
@@ -334,7 +334,7 @@ RT_DEV bool trace_closest(const DScene &S, Ray ray, LaneStack st, Hit &h, Tally<
         const float c = dot(r.p, r.p) - 1.0f;
         const float disc = b * b - 4 * a * c;
         if (disc < 0.0f) continue;
-        const float s = __fsqrt_rn(disc);
+        const float s = fsqrt(disc);
         const float inv2a = 1.0f / (2.0f * a);
         const float t1 = (-b - s) * inv2a;
         if (t1 <= 0.0f) continue;

@@ -154,6 +154,7 @@ class Context:
     def __init__(self, device=0):
         self._L = load()
         self._h = C.c_void_p()
+        self.width = self.height = 1
         rc = self._L.rt_init(device, C.byref(self._h))
         if rc:
             raise RtError(rc, self._L.rt_last_error(None).decode())
