@@ -1,8 +1,11 @@
 // gfx950 kernels of the rendering hot path.
 //
-//   k_paths    one lane = one (pixel, sample) camera path: seeds its PCG stream,
-//              builds the camera ray (src/main.cpp:294-323) and runs the path
-//              integrator; writes the sample's radiance to the sample buffer
+//   k_paths    persistent kernel, one lane = one (pixel, sample) camera path at a
+//              time: seeds its PCG stream, builds the camera ray
+//              (src/main.cpp:294-323), runs the path integrator one bounce per
+//              loop trip and writes the sample's radiance to the sample buffer.
+//              A lane whose path has ended takes the next path from a work queue,
+//              so a wave stays full although path lengths vary from 1 to 50 bounces.
 //   k_resolve  one lane = one pixel: in-order running sums over the new samples,
 //              the variance stop test (src/main.cpp:357-372), and for finished
 //              pixels the mean, sRGB and 8-bit quantisation (src/main.cpp:375-380)
@@ -31,12 +34,11 @@ struct PixelState {
     int32_t pad;
 };
 
-RT_DEV LaneStack lane_stack(uint32_t *lds, int levels)
+static_assert(kBlock == (int)kStackStride, "stack[level][thread] layout assumes one block per stride");
+RT_DEV LaneStack lane_stack(uint32_t *lds)
 {
     LaneStack st;
     st.id = lds + threadIdx.x;
-    st.t = reinterpret_cast<float *>(lds + levels * kBlock) + threadIdx.x;
-    st.stride = kBlock;
     return st;
 }
 
@@ -93,44 +95,92 @@ RT_DEV Ray camera_ray(const DFrame &F, const float *halton, int i, int j, int k,
     return r;
 }
 
-template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_paths(DScene S, DFrame F, const float *__restrict__ halton,
+// Work queue of a launch: items [0, n_items) are handed out in chunks; a wave draws a
+// chunk with one atomic and feeds its lanes from it, so the queue word sees one
+// atomic per kChunk paths.
+constexpr uint32_t kChunk = 512;
+
+#ifndef RT_PATHS_MIN_WAVES
+#define RT_PATHS_MIN_WAVES 1 // waves per SIMD the register allocator must leave room for
+#endif
+
+template <bool COUNT, int LEVELS>
+__global__ __launch_bounds__(kBlock, RT_PATHS_MIN_WAVES) void k_paths(DScene S, DFrame F, const float *__restrict__ halton,
                                                   const int32_t *__restrict__ active, uint64_t n_items, int k0, int nk,
-                                                  float4 *__restrict__ sbuf, FramePlanes out, DCounters *ctr)
+                                                  float4 *__restrict__ sbuf, FramePlanes out, DCounters *ctr,
+                                                  unsigned long long *queue)
 {
     extern __shared__ uint32_t lds[];
-    const LaneStack st = lane_stack(lds, S.stack_levels);
-    const uint64_t item = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    const LaneStack st = lane_stack(lds);
+    const uint32_t lane = threadIdx.x & 63u;
     PathTally pt;
     Tally<COUNT> tl;
     uint32_t paths = 0;
-    if (item < n_items) {
-        const uint32_t a = (uint32_t)(item / (uint32_t)nk);
-        const int kk = (int)(item - (uint64_t)a * (uint32_t)nk);
-        const int k = k0 + kk;
-        const int pix = active[a];
-        const int i = pix % F.width, j = pix / F.width;
-        const uint64_t ps = pixel_seed(F.seed, (uint64_t)pix);
-        Rng rng;
-        rng_set_sequence(rng, 0, ps);
-        float off[4];
-        off[0] = rng_float(rng); off[1] = rng_float(rng); off[2] = rng_float(rng); off[3] = rng_float(rng);
-        rng_set_sequence(rng, (uint64_t)k + 1, ps);
-        const Ray ray = camera_ray(F, halton, i, j, k, off);
-        float fz = FLT_MAX; int fid = -1;
-        if (k == 0 && F.max_bounces <= 0) { // no bounce loop to take the depth / id planes from
-            Hit h;
-            Tally<false> none;
-            const bool hit = trace_closest<false>(S, ray, st, h, none);
-            fz = h.z; fid = hit ? h.node : -1;
+
+    // wave-uniform queue window, per-lane path
+    uint64_t chunk_next = 0, chunk_end = 0;
+    bool exhausted = false;
+    bool alive = false;
+    uint64_t item = 0;
+    int pix = 0, k = 0;
+    float fz = FLT_MAX; int fid = -1;
+    PathState ps;
+    path_begin(ps, Ray{mk(0, 0, 0), mk(0, 0, 1)});
+    ps.rng.state = 0; ps.rng.inc = 1;
+
+    for (;;) {
+        const uint64_t need = __ballot(!alive);
+        if (need != 0) {
+            if (chunk_next >= chunk_end && !exhausted) {
+                unsigned long long b = 0;
+                if (lane == 0) b = atomicAdd(queue, (unsigned long long)kChunk);
+                b = __shfl(b, 0, 64);
+                chunk_next = b < n_items ? b : n_items;
+                chunk_end = b + kChunk < n_items ? b + kChunk : n_items;
+                if (chunk_next >= chunk_end) exhausted = true;
+            }
+            const uint64_t avail = chunk_end - chunk_next;
+            const uint32_t want = (uint32_t)__popcll(need);
+            const uint32_t take = avail < want ? (uint32_t)avail : want;
+            const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+            if (!alive && rank < take) {
+                item = chunk_next + rank;
+                const uint32_t a = (uint32_t)(item / (uint32_t)nk);
+                k = k0 + (int)(item - (uint64_t)a * (uint32_t)nk);
+                pix = active[a];
+                const int i = pix % F.width, j = pix / F.width;
+                const uint64_t seed = pixel_seed(F.seed, (uint64_t)pix);
+                rng_set_sequence(ps.rng, 0, seed);
+                float off[4];
+                off[0] = rng_float(ps.rng); off[1] = rng_float(ps.rng); off[2] = rng_float(ps.rng); off[3] = rng_float(ps.rng);
+                rng_set_sequence(ps.rng, (uint64_t)k + 1, seed);
+                path_begin(ps, camera_ray(F, halton, i, j, k, off));
+                fz = FLT_MAX; fid = -1;
+                if (k == 0 && F.max_bounces <= 0) { // no bounce loop to take the depth / id planes from
+                    Hit h;
+                    Tally<false> none;
+                    const bool hit = trace_closest<false, LEVELS>(S, ps.ray, st, h, none);
+                    fz = h.z; fid = hit ? h.node : -1;
+                }
+                alive = true;
+                ++paths;
+            }
+            chunk_next += take;
         }
-        const V3 c = trace_path<COUNT>(S, F, ray, rng, st, pt, tl, &fz, &fid);
-        if (k == 0) {
-            if (out.z) out.z[pix] = fz;
-            if (out.object_id) out.object_id[pix] = fid;
+        if (!__any(alive)) {
+            if (exhausted) break; // every wave gets here: the queue only grows
+            continue;
         }
-        sbuf[item] = make_float4(c.x, c.y, c.z, 0.0f);
-        paths = 1;
+        if (alive) {
+            if (!path_step<COUNT, LEVELS>(S, F, ps, st, pt, tl, &fz, &fid)) {
+                if (k == 0) {
+                    if (out.z) out.z[pix] = fz;
+                    if (out.object_id) out.object_id[pix] = fid;
+                }
+                sbuf[item] = make_float4(ps.result.x, ps.result.y, ps.result.z, 0.0f);
+                alive = false;
+            }
+        }
     }
     flush_counters<COUNT>(ctr, pt, tl, paths);
 }
@@ -201,14 +251,14 @@ __global__ __launch_bounds__(kBlock) void k_resolve(DFrame F, const int32_t *__r
 __global__ __launch_bounds__(kBlock) void k_trace(DScene S, const float *__restrict__ rays6, int n, rt_hit *__restrict__ out)
 {
     extern __shared__ uint32_t lds[];
-    const LaneStack st = lane_stack(lds, S.stack_levels);
+    const LaneStack st = lane_stack(lds);
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     Ray r;
     r.p = ld3(rays6 + (size_t)i * 6); r.d = ld3(rays6 + (size_t)i * 6 + 3);
     Hit h;
     Tally<false> tl;
-    const bool hit = trace_closest<false>(S, r, st, h, tl);
+    const bool hit = trace_closest<false, kMaxSceneDepth - 1>(S, r, st, h, tl);
     if (hit && h.node >= 0) finish_hit(S, r, h, true);
     else { h.p = mk(0, 0, 0); h.n = mk(0, 0, 0); h.uvw = mk(0.5f, 0.5f, 0.5f); }
     rt_hit o;
@@ -225,20 +275,20 @@ __global__ __launch_bounds__(kBlock) void k_trace_shadow(DScene S, const float *
                                                          const float *__restrict__ t_max, int n, int32_t *__restrict__ out)
 {
     extern __shared__ uint32_t lds[];
-    const LaneStack st = lane_stack(lds, S.stack_levels);
+    const LaneStack st = lane_stack(lds);
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     Ray r;
     r.p = ld3(rays6 + (size_t)i * 6); r.d = ld3(rays6 + (size_t)i * 6 + 3);
     Tally<false> tl;
-    out[i] = trace_shadow<false>(S, r, t_max[i], st, tl) ? 1 : 0;
+    out[i] = trace_shadow<false, kMaxSceneDepth - 1>(S, r, t_max[i], st, tl) ? 1 : 0;
 }
 
 __global__ __launch_bounds__(kBlock) void k_trace_paths(DScene S, DFrame F, const float *__restrict__ rays6, int n,
                                                         float *__restrict__ radiance3, DCounters *ctr)
 {
     extern __shared__ uint32_t lds[];
-    const LaneStack st = lane_stack(lds, S.stack_levels);
+    const LaneStack st = lane_stack(lds);
     const int i = blockIdx.x * kBlock + threadIdx.x;
     PathTally pt;
     Tally<false> tl;
@@ -248,7 +298,11 @@ __global__ __launch_bounds__(kBlock) void k_trace_paths(DScene S, DFrame F, cons
         r.p = ld3(rays6 + (size_t)i * 6); r.d = ld3(rays6 + (size_t)i * 6 + 3);
         Rng rng;
         rng_set_sequence(rng, (uint64_t)i + 1, F.seed);
-        const V3 c = trace_path<false>(S, F, r, rng, st, pt, tl, nullptr, nullptr);
+        PathState ps;
+        path_begin(ps, r);
+        ps.rng = rng;
+        while (path_step<false, kMaxSceneDepth - 1>(S, F, ps, st, pt, tl, nullptr, nullptr)) {}
+        const V3 c = ps.result;
         radiance3[(size_t)i * 3] = c.x; radiance3[(size_t)i * 3 + 1] = c.y; radiance3[(size_t)i * 3 + 2] = c.z;
         paths = 1;
     }

@@ -187,80 +187,99 @@ struct PathTally {
     uint32_t closest = 0, shadow = 0;
 };
 
-// tracePath (src/main.cpp:160-268).  first_hit receives z and node id of the
-// first closest-hit query when non-null (used for the depth / id planes).
-template <bool COUNT>
-RT_DEV V3 trace_path(const DScene &S, const DFrame &F, Ray ray, Rng &rng, LaneStack st, PathTally &pt,
-                     Tally<COUNT> &tl, float *first_z, int *first_id)
+// One camera path in flight.  A lane keeps this across bounces and swaps in a
+// fresh one when the path ends, so a wave stays full however uneven path lengths are.
+struct PathState {
+    Ray ray;
+    V3 throughput, result;
+    Rng rng;
+    float lastProb;
+    int lastLobe;
+    int bounce;
+};
+
+RT_DEV void path_begin(PathState &ps, Ray ray)
 {
-    V3 throughput = mk(1.0f, 1.0f, 1.0f);
-    V3 result = mk(0.0f, 0.0f, 0.0f);
+    ps.ray = ray;
+    ps.throughput = mk(1.0f, 1.0f, 1.0f);
+    ps.result = mk(0.0f, 0.0f, 0.0f);
+    ps.lastProb = 1.0f;
+    ps.lastLobe = LOBE_NONE;
+    ps.bounce = 0;
+}
+
+// One iteration of the bounce loop of tracePath (src/main.cpp:170-265).  Returns
+// false when the path has ended; ps.result then holds its radiance.  first_z /
+// first_id receive depth and node id of the camera ray's hit when non-null.
+template <bool COUNT, int LEVELS>
+RT_DEV bool path_step(const DScene &S, const DFrame &F, PathState &ps, LaneStack st, PathTally &pt,
+                      Tally<COUNT> &tl, float *first_z, int *first_id)
+{
+    if (ps.bounce >= F.max_bounces) return false;
     const rt_light &light = S.lights[0];
     const float bias = F.bias;
-    float lastProb = 1.0f;
-    int lastLobe = LOBE_NONE;
-    for (int bounce = 0; bounce < F.max_bounces; ++bounce) {
-        Hit h;
-        ++pt.closest;
-        const bool hit = trace_closest<COUNT>(S, ray, st, h, tl);
-        if (bounce == 0 && first_z) { *first_z = h.z; *first_id = hit ? h.node : -1; }
-        if (!hit) {
-            result = result + ld3(S.background) * throughput; // main.cpp:175-176
-            return result;
-        }
-        if (h.node < 0) { // light (main.cpp:184-210)
-            const V3 rad = light_radiance(light);
-            if (bounce == 0) result = result + rad * throughput;
-            else {
-                float weight = 1.0f;
-                if (lastLobe == LOBE_DIFFUSE) {
-                    const float lp = light_pdf(light, ray.p, ray.d);
-                    if (lp > 0.0f) weight = (lastProb * lastProb) / (lastProb * lastProb + lp * lp);
-                }
-                result = result + (rad * throughput) * weight;
-            }
-            return result;
-        }
-        finish_hit(S, ray, h, false);
-        Surface s; // SamplerInfo::SetHit (renderer.h:145-153)
-        const V3 normal = normalize(h.n);
-        s.p = h.p; s.n = normal; s.v = -normalize(ray.d); s.front = h.front;
-        const rt_material &mtl = S.materials[S.nodes[h.node].material];
-
-        // next-event estimation (main.cpp:214-251)
-        Sample ne;
-        light_generate(light, s.p, rng, ne);
-        {
-            const float sign = h.front ? 1.0f : -1.0f;
-            Ray sr;
-            sr.p = h.p + (normal * bias) * sign;
-            sr.d = ne.dir;
-            ++pt.shadow;
-            if (!trace_shadow<COUNT>(S, sr, ne.dist - bias, st, tl)) {
-                const float cosS = std_max(0.0f, dot(normal, sr.d));
-                if (cosS > 0.0f && ne.prob > 0.0f) {
-                    const float mp = mtl_pdf(mtl, s, ne.dir);
-                    float weight = 1.0f;
-                    if (mp > 0.0f) weight = (ne.prob * ne.prob) / (ne.prob * ne.prob + mp * mp);
-                    // the specular term of main.cpp:241-246 is gated on a field that
-                    // GetSampleInfo never writes (it reads as NONE): diffuse only
-                    const V3 brdf = ld3(mtl.diffuse) / kPi;
-                    result = result + ((((brdf * cosS) * ne.mult) * weight) / ne.prob) * throughput;
-                }
-            }
-        }
-
-        // indirect bounce (main.cpp:253-264)
-        Sample in;
-        if (!mtl_generate(mtl, s, rng, in)) break;
-        lastProb = in.prob;
-        lastLobe = in.lobe;
-        ray.d = in.dir;
-        const float sign = (dot(normal, ray.d) > 0.0f) ? 1.0f : -1.0f;
-        ray.p = h.p + (normal * bias) * sign;
-        throughput = throughput * (in.mult / in.prob);
+    const Ray ray = ps.ray;
+    Hit h;
+    ++pt.closest;
+    const bool hit = trace_closest<COUNT, LEVELS>(S, ray, st, h, tl);
+    if (ps.bounce == 0 && first_z) { *first_z = h.z; *first_id = hit ? h.node : -1; }
+    if (!hit) {
+        ps.result = ps.result + ld3(S.background) * ps.throughput; // main.cpp:175-176
+        return false;
     }
-    return result;
+    if (h.node < 0) { // light (main.cpp:184-210)
+        const V3 rad = light_radiance(light);
+        if (ps.bounce == 0) ps.result = ps.result + rad * ps.throughput;
+        else {
+            float weight = 1.0f;
+            if (ps.lastLobe == LOBE_DIFFUSE) {
+                const float lp = light_pdf(light, ray.p, ray.d);
+                if (lp > 0.0f) weight = (ps.lastProb * ps.lastProb) / (ps.lastProb * ps.lastProb + lp * lp);
+            }
+            ps.result = ps.result + (rad * ps.throughput) * weight;
+        }
+        return false;
+    }
+    finish_hit(S, ray, h, false);
+    Surface s; // SamplerInfo::SetHit (renderer.h:145-153)
+    const V3 normal = normalize(h.n);
+    s.p = h.p; s.n = normal; s.v = -normalize(ray.d); s.front = h.front;
+    const rt_material &mtl = S.materials[S.nodes[h.node].material];
+
+    // next-event estimation (main.cpp:214-251)
+    Sample ne;
+    light_generate(light, s.p, ps.rng, ne);
+    {
+        const float sign = h.front ? 1.0f : -1.0f;
+        Ray sr;
+        sr.p = h.p + (normal * bias) * sign;
+        sr.d = ne.dir;
+        ++pt.shadow;
+        if (!trace_shadow<COUNT, LEVELS>(S, sr, ne.dist - bias, st, tl)) {
+            const float cosS = std_max(0.0f, dot(normal, sr.d));
+            if (cosS > 0.0f && ne.prob > 0.0f) {
+                const float mp = mtl_pdf(mtl, s, ne.dir);
+                float weight = 1.0f;
+                if (mp > 0.0f) weight = (ne.prob * ne.prob) / (ne.prob * ne.prob + mp * mp);
+                // the specular term of main.cpp:241-246 is gated on a field that
+                // GetSampleInfo never writes (it reads as NONE): diffuse only
+                const V3 brdf = ld3(mtl.diffuse) / kPi;
+                ps.result = ps.result + ((((brdf * cosS) * ne.mult) * weight) / ne.prob) * ps.throughput;
+            }
+        }
+    }
+
+    // indirect bounce (main.cpp:253-264)
+    Sample in;
+    if (!mtl_generate(mtl, s, ps.rng, in)) return false;
+    ps.lastProb = in.prob;
+    ps.lastLobe = in.lobe;
+    ps.ray.d = in.dir;
+    const float sign = (dot(normal, in.dir) > 0.0f) ? 1.0f : -1.0f;
+    ps.ray.p = h.p + (normal * bias) * sign;
+    ps.throughput = ps.throughput * (in.mult / in.prob);
+    ++ps.bounce;
+    return true;
 }
 
 } // namespace rtd

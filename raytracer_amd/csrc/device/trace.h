@@ -26,10 +26,13 @@ struct Hit {
     float u, v;
 };
 
+// Per-lane BVH stack in LDS, 4 bytes per entry (node id only): entry k of thread t
+// is at ids[k * kStackStride + t].  The entry distance the reference keeps next to the
+// id (src/TriObj.cpp:15,35-37) is recomputed from the node's bounds when it is popped;
+// it is a pure function of ray and bounds, so the value is the same.
+constexpr uint32_t kStackStride = 256;
 struct LaneStack {
-    uint32_t *id; // &lds_ids[threadIdx.x], stride blockDim.x
-    float *t;     // &lds_t[threadIdx.x]
-    uint32_t stride;
+    uint32_t *id; // &lds_ids[threadIdx.x]
 };
 
 template <bool COUNT> struct Tally {
@@ -128,6 +131,16 @@ RT_DEV bool bvh_box(V3 p, V3 inv, float t_max, float4 b0, float4 b1, float &dist
     return false;
 }
 
+// entry distance of the slab test above without the early outs (same operations, same bits)
+RT_DEV float bvh_near(V3 p, V3 inv, float4 b0, float4 b1)
+{
+    float tNear = 0.0f;
+    tNear = std_max(tNear, std_min((b0.x - p.x) * inv.x, (b0.w - p.x) * inv.x));
+    tNear = std_max(tNear, std_min((b0.y - p.y) * inv.y, (b1.x - p.y) * inv.y));
+    tNear = std_max(tNear, std_min((b0.z - p.z) * inv.z, (b1.y - p.z) * inv.z));
+    return tNear;
+}
+
 // one Moeller-Trumbore test (src/TriObj.cpp:46-74) up to, not including, the range test on t
 RT_DEV bool tri_test(const float4 *rec, Ray r, float &t, float &u, float &v, float &det, uint32_t &face)
 {
@@ -167,15 +180,15 @@ RT_DEV bool mesh_closest(const DMesh &M, Ray r, LaneStack st, float &tOut, uint3
         float dist;
         tl.boxes(1);
         if (!bvh_box(r.p, inv, closestT, M.bvh[2], M.bvh[3], dist)) return false;
-        st.id[0] = 1; st.t[0] = dist; sp = 1;
+        st.id[0] = 1; sp = 1;
     }
     bool hit = false;
     while (sp > 0) {
         --sp;
-        const uint32_t id = st.id[sp * st.stride];
-        const float nodeT = st.t[sp * st.stride];
-        if (closestT < nodeT) continue;
-        const uint32_t data = __float_as_uint(M.bvh[id * 2 + 1].z);
+        const uint32_t id = st.id[sp * kStackStride];
+        const float4 n0 = M.bvh[id * 2], n1 = M.bvh[id * 2 + 1];
+        if (closestT < bvh_near(r.p, inv, n0, n1)) continue; // entered farther than the best hit so far
+        const uint32_t data = __float_as_uint(n1.z);
         if (data & kLeafBit) {
             const uint32_t off = data & 0x0FFFFFFFu;
             const uint32_t cnt = ((data >> 28) & 7u) + 1;
@@ -200,11 +213,11 @@ RT_DEV bool mesh_closest(const DMesh &M, Ray r, LaneStack st, float &tOut, uint3
         if (h1 && h2) {
             // nearer child on top of the stack; on a tie the second child is visited first
             const bool firstNear = d1 < d2;
-            st.id[sp * st.stride] = firstNear ? c2 : c1; st.t[sp * st.stride] = firstNear ? d2 : d1; ++sp;
-            st.id[sp * st.stride] = firstNear ? c1 : c2; st.t[sp * st.stride] = firstNear ? d1 : d2; ++sp;
+            st.id[sp * kStackStride] = firstNear ? c2 : c1; ++sp;
+            st.id[sp * kStackStride] = firstNear ? c1 : c2; ++sp;
             continue;
         }
-        st.id[sp * st.stride] = h1 ? c1 : c2; st.t[sp * st.stride] = h1 ? d1 : d2; ++sp;
+        st.id[sp * kStackStride] = h1 ? c1 : c2; ++sp;
     }
     tOut = closestT;
     return hit;
@@ -226,7 +239,7 @@ RT_DEV bool mesh_shadow(const DMesh &M, Ray r, float t_max, LaneStack st, Tally<
     }
     while (sp > 0) {
         --sp;
-        const uint32_t id = st.id[sp * st.stride];
+        const uint32_t id = st.id[sp * kStackStride];
         const uint32_t data = __float_as_uint(M.bvh[id * 2 + 1].z);
         if (data & kLeafBit) {
             const uint32_t off = data & 0x0FFFFFFFu;
@@ -249,11 +262,11 @@ RT_DEV bool mesh_shadow(const DMesh &M, Ray r, float t_max, LaneStack st, Tally<
         if (!h1 && !h2) continue;
         if (h1 && h2) {
             const bool firstNear = d1 < d2;
-            st.id[sp * st.stride] = firstNear ? c2 : c1; ++sp;
-            st.id[sp * st.stride] = firstNear ? c1 : c2; ++sp;
+            st.id[sp * kStackStride] = firstNear ? c2 : c1; ++sp;
+            st.id[sp * kStackStride] = firstNear ? c1 : c2; ++sp;
             continue;
         }
-        st.id[sp * st.stride] = h1 ? c1 : c2; ++sp;
+        st.id[sp * kStackStride] = h1 ? c1 : c2; ++sp;
     }
     return false;
 }
@@ -268,26 +281,30 @@ RT_DEV Ray sel(bool c, Ray a, Ray b)
     o.d = mk(selq(c, a.d.x, b.d.x), selq(c, a.d.y, b.d.y), selq(c, a.d.z, b.d.z));
     return o;
 }
-struct RayLevels {
+// LEVELS = number of hierarchy levels that have children (1 for a flat scene: only
+// the root); the kernels are instantiated for 1, 2 and kMaxSceneDepth-1 so that flat
+// scenes do not pay registers for levels they do not have.
+template <int LEVELS> struct RayLevels {
     Ray r0, r1, r2, r3, r4;
-    static_assert(kMaxSceneDepth == 6, "levels 0..4 can be parents; level 5 is always a leaf level");
-    // local ray of the node at depth d (d <= 4)
+    static_assert(kMaxSceneDepth == 6 && LEVELS >= 1 && LEVELS <= 5, "levels 0..4 can be parents");
+    // local ray of the node at depth d (d < LEVELS)
     RT_DEV Ray get(int d) const
     {
         Ray o = r0;
-        o = sel(d == 1, r1, o);
-        o = sel(d == 2, r2, o);
-        o = sel(d == 3, r3, o);
-        o = sel(d == 4, r4, o);
+        if constexpr (LEVELS > 1) o = sel(d == 1, r1, o);
+        if constexpr (LEVELS > 2) o = sel(d == 2, r2, o);
+        if constexpr (LEVELS > 3) o = sel(d == 3, r3, o);
+        if constexpr (LEVELS > 4) o = sel(d == 4, r4, o);
         return o;
     }
     RT_DEV void set(int d, Ray v)
     {
+        if constexpr (LEVELS == 1) { r0 = v; return; }
         r0 = sel(d == 0, v, r0);
-        r1 = sel(d == 1, v, r1);
-        r2 = sel(d == 2, v, r2);
-        r3 = sel(d == 3, v, r3);
-        r4 = sel(d == 4, v, r4);
+        if constexpr (LEVELS > 1) r1 = sel(d == 1, v, r1);
+        if constexpr (LEVELS > 2) r2 = sel(d == 2, v, r2);
+        if constexpr (LEVELS > 3) r3 = sel(d == 3, v, r3);
+        if constexpr (LEVELS > 4) r4 = sel(d == 4, v, r4);
     }
     RT_DEV void init(Ray v) { r0 = r1 = r2 = r3 = r4 = v; }
 };
@@ -295,11 +312,11 @@ struct RayLevels {
 // shootRay + shootRayAtLights (src/main.cpp:16-70,115-120).  The winner is the
 // first hit in depth-first order with the smallest z (strict <), which is what
 // the reference's per-level comparisons select.
-template <bool COUNT>
+template <bool COUNT, int LEVELS>
 RT_DEV bool trace_closest(const DScene &S, Ray ray, LaneStack st, Hit &h, Tally<COUNT> &tl)
 {
     h.z = FLT_MAX; h.node = -1; h.front = 1; h.face = 0; h.u = 0; h.v = 0;
-    RayLevels lv;
+    RayLevels<LEVELS> lv;
     lv.init(ray);
     const int n = S.n_nodes;
     for (int i = 0; i < n; ++i) {
@@ -384,10 +401,10 @@ RT_DEV void finish_hit(const DScene &S, Ray ray, Hit &h, bool want_uvw)
 }
 
 // shootShadowRay (src/main.cpp:72-89,122-125): any hit with t < t_max
-template <bool COUNT>
+template <bool COUNT, int LEVELS>
 RT_DEV bool trace_shadow(const DScene &S, Ray ray, float t_max, LaneStack st, Tally<COUNT> &tl)
 {
-    RayLevels lv;
+    RayLevels<LEVELS> lv;
     lv.init(ray);
     const int n = S.n_nodes;
     for (int i = 0; i < n; ++i) {

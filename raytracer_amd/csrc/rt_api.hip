@@ -55,7 +55,9 @@ struct rt_ctx {
     bool have_camera = false;
     rt_camera camera{};
     // frame
-    DeviceBuf d_halton, d_active[2], d_next_count, d_state, d_sbuf, d_counters;
+    DeviceBuf d_halton, d_active[2], d_next_count, d_state, d_sbuf, d_counters, d_queue;
+    int n_cu = 256;
+    int ray_levels = 1; // hierarchy levels that have children
     DeviceBuf d_rgb, d_z, d_cnt, d_id, d_lin; // internal planes when the caller wants host output
     DeviceBuf d_q_in, d_q_aux, d_q_out;       // batch queries
     std::vector<int32_t> active_host;
@@ -141,7 +143,14 @@ void fill_frame(const rt_ctx *ctx, const rt_render_params *p, DFrame &F)
     F.max_bounces = p->max_bounces; F.bias = p->bias; F.halton_period = p->halton_period; F.seed = p->seed;
 }
 
-size_t stack_lds_bytes(const DScene &S) { return (size_t)S.stack_levels * kBlock * 8; }
+const void *paths_kernel(bool counting, int ray_levels)
+{
+    if (ray_levels <= 1) return counting ? (const void *)k_paths<true, 1> : (const void *)k_paths<false, 1>;
+    if (ray_levels == 2) return counting ? (const void *)k_paths<true, 2> : (const void *)k_paths<false, 2>;
+    return counting ? (const void *)k_paths<true, 5> : (const void *)k_paths<false, 5>;
+}
+
+size_t stack_lds_bytes(const DScene &S) { return (size_t)S.stack_levels * kBlock * 4; }
 
 } // namespace
 
@@ -175,9 +184,14 @@ int rt_init(int device, rt_ctx **out)
     if ((e = ctx->d_counters.reserve(sizeof(DCounters))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = ctx->d_next_count.reserve(sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
     // per-lane BVH stacks may need more than the default 64 KiB of LDS per workgroup
-    for (const void *k : {(const void *)k_paths<false>, (const void *)k_paths<true>, (const void *)k_trace,
-                          (const void *)k_trace_shadow, (const void *)k_trace_paths})
+    for (const void *k : {(const void *)k_paths<false, 1>, (const void *)k_paths<false, 2>, (const void *)k_paths<false, 5>,
+                          (const void *)k_paths<true, 1>, (const void *)k_paths<true, 2>, (const void *)k_paths<true, 5>,
+                          (const void *)k_trace, (const void *)k_trace_shadow, (const void *)k_trace_paths})
         (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
+    ctx->n_cu = prop.multiProcessorCount;
+    if ((e = ctx->d_queue.reserve(sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
     *out = ctx;
     return RT_OK;
 }
@@ -209,6 +223,7 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc)
     const uint32_t nn = sc->n_nodes;
     std::vector<DNode> nodes(nn);
     int max_mesh_depth = -1;
+    int ray_levels = 1;
     for (uint32_t i = 0; i < nn; ++i) {
         const rt_node &n = sc->nodes[i];
         if ((i == 0 && n.parent != -1) || (i > 0 && (n.parent < 0 || n.parent >= (int)i)))
@@ -226,6 +241,7 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc)
             while (a >= 0 && a != n.parent) a = nodes[a].parent;
             if (a != n.parent) return ctx->fail(RT_ERR_INVALID, "node %u: not in depth-first order", i);
             nodes[n.parent].has_children = 1;
+            ray_levels = std::max(ray_levels, nodes[n.parent].depth + 1);
             memcpy(d.chain, nodes[n.parent].chain, sizeof d.chain);
         }
         d.chain[d.depth] = (int)i;
@@ -327,6 +343,7 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc)
     memcpy(S.background, sc->background, 12);
     ctx->mesh_bufs.swap(bufs);
     ctx->scene = S;
+    ctx->ray_levels = ray_levels;
     ctx->have_scene = true;
     return RT_OK;
 }
@@ -420,15 +437,27 @@ int rt_render(rt_ctx *ctx, const rt_render_params *prm, rt_frame_out *out)
         for (uint32_t first = 0; first < n_active; first += chunk_px) {
             const uint32_t cnt = std::min(chunk_px, n_active - first);
             const uint64_t items = (uint64_t)cnt * nk;
-            const dim3 grid((unsigned)((items + kBlock - 1) / kBlock));
             const int32_t *act = ctx->d_active[cur].as<int32_t>() + first;
+            // persistent launch: as many workgroups as the chip holds at once (more would only queue up)
+            const void *fn = paths_kernel(ctx->counting, ctx->ray_levels);
+            int per_cu = 1;
+            HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kBlock, lds));
+            per_cu = std::max(1, std::min(per_cu, 8));
+            const uint64_t want_blocks = (items + kBlock - 1) / kBlock;
+            const dim3 grid((unsigned)std::min<uint64_t>(want_blocks, (uint64_t)ctx->n_cu * per_cu));
+            HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue.p, 0, sizeof(unsigned long long), s));
             HIP_TRY(ctx, hipEventRecord(ctx->evk0, s));
-            if (ctx->counting)
-                hipLaunchKernelGGL(k_paths<true>, grid, dim3(kBlock), lds, s, ctx->scene, F, ctx->d_halton.as<float>(), act, items,
-                                   k0, nk, ctx->d_sbuf.as<float4>(), P, ctx->d_counters.as<DCounters>());
-            else
-                hipLaunchKernelGGL(k_paths<false>, grid, dim3(kBlock), lds, s, ctx->scene, F, ctx->d_halton.as<float>(), act, items,
-                                   k0, nk, ctx->d_sbuf.as<float4>(), P, ctx->d_counters.as<DCounters>());
+            {
+                DScene a_scene = ctx->scene;
+                const float *a_hal = ctx->d_halton.as<float>();
+                uint64_t a_items = items;
+                int a_k0 = k0, a_nk = nk;
+                float4 *a_sbuf = ctx->d_sbuf.as<float4>();
+                DCounters *a_ctr = ctx->d_counters.as<DCounters>();
+                unsigned long long *a_queue = ctx->d_queue.as<unsigned long long>();
+                void *args[] = {&a_scene, &F, &a_hal, &act, &a_items, &a_k0, &a_nk, &a_sbuf, &P, &a_ctr, &a_queue};
+                HIP_TRY(ctx, hipLaunchKernel(fn, grid, dim3(kBlock), args, lds, s));
+            }
             HIP_TRY(ctx, hipGetLastError());
             HIP_TRY(ctx, hipEventRecord(ctx->evk1, s));
             hipLaunchKernelGGL(k_resolve, dim3((cnt + kBlock - 1) / kBlock), dim3(kBlock), 0, s, F, act, cnt, k0, nk,
