@@ -101,7 +101,7 @@ RT_DEV Ray camera_ray(const DFrame &F, const float *halton, int i, int j, int k,
 constexpr uint32_t kChunk = 512;
 
 #ifndef RT_PATHS_MIN_WAVES
-#define RT_PATHS_MIN_WAVES 1 // waves per SIMD the register allocator must leave room for
+#define RT_PATHS_MIN_WAVES 6 // waves per SIMD the register allocator must leave room for
 #endif
 
 template <bool COUNT, int LEVELS>

@@ -101,51 +101,78 @@ RT_DEV bool plane_shadow(Ray r, float t_max)
     return t < t_max;
 }
 
+constexpr uint32_t kLeafBit = 0x80000000u;
+
+// Mesh arrays are reached through pointers that were themselves loaded from memory, so
+// the compiler cannot infer their address space and would use flat loads (which wait on
+// two counters); they are device-global by construction, and saying so gives global loads.
+#define RT_GLOBAL_AS __attribute__((address_space(1)))
+typedef float f4 __attribute__((ext_vector_type(4))); // native vector: loadable from any address space
+typedef const RT_GLOBAL_AS f4 *GF4;
+typedef const RT_GLOBAL_AS float *GF32;
+typedef const RT_GLOBAL_AS uint32_t *GU32;
+RT_DEV V3 gld3(GF32 p) { return mk(p[0], p[1], p[2]); }
+
 // ---- BVH slab test (src/TriObj.cpp:272-320); inv = 1/dir computed once per ray ----
-RT_DEV bool bvh_box(V3 p, V3 inv, float t_max, float4 b0, float4 b1, float &dist)
+// Written without the early returns of the reference: the three slabs are always
+// evaluated and the three "tNear > tFar" rejects are combined at the end.  The
+// result is the same predicate and the same entry distance (it is a pure function
+// of its inputs), but the node's bounds are fetched with one group of wide loads
+// instead of three dependent partial ones.
+//
+// EXACT selects with std::min/std::max operand order, so a NaN (0 * inf: a ray
+// direction component of exactly 0 with the origin exactly on a slab plane) goes
+// where it goes in the reference.  The fast form uses the min/max instructions; it
+// is used only for rays whose 1/dir is finite in all three components, for which no
+// NaN can arise and both forms agree in every bit that is compared.
+template <bool EXACT> RT_DEV float bmin(float a, float b) { return EXACT ? std_min(a, b) : fminf(a, b); }
+template <bool EXACT> RT_DEV float bmax(float a, float b) { return EXACT ? std_max(a, b) : fmaxf(a, b); }
+
+template <bool EXACT>
+RT_DEV bool bvh_box_t(V3 p, V3 inv, float t_max, f4 b0, f4 b1, float &dist)
 {
     float tNear = 0.0f;
     float tFar = t_max;
     float t1 = (b0.x - p.x) * inv.x;
     float t2 = (b0.w - p.x) * inv.x;
-    float smin = std_min(t1, t2);
-    float smax = std_max(t2, t1);
-    tNear = std_max(tNear, smin);
-    tFar = std_min(tFar, smax);
-    if (tNear > tFar) return false;
+    tNear = bmax<EXACT>(tNear, bmin<EXACT>(t1, t2));
+    tFar = bmin<EXACT>(tFar, bmax<EXACT>(t2, t1));
+    bool ok = !(tNear > tFar);
     t1 = (b0.y - p.y) * inv.y;
     t2 = (b1.x - p.y) * inv.y;
-    smin = std_min(t1, t2);
-    smax = std_max(t1, t2);
-    tNear = std_max(tNear, smin);
-    tFar = std_min(tFar, smax);
-    if (tNear > tFar) return false;
+    tNear = bmax<EXACT>(tNear, bmin<EXACT>(t1, t2));
+    tFar = bmin<EXACT>(tFar, bmax<EXACT>(t1, t2));
+    ok = ok && !(tNear > tFar);
     t1 = (b0.z - p.z) * inv.z;
     t2 = (b1.y - p.z) * inv.z;
-    smin = std_min(t1, t2);
-    smax = std_max(t1, t2);
-    tNear = std_max(tNear, smin);
-    tFar = std_min(tFar, smax);
-    if (tNear > tFar) return false;
-    if (tNear < tFar) { dist = tNear; return true; }
-    return false;
+    tNear = bmax<EXACT>(tNear, bmin<EXACT>(t1, t2));
+    tFar = bmin<EXACT>(tFar, bmax<EXACT>(t1, t2));
+    ok = ok && !(tNear > tFar) && (tNear < tFar);
+    dist = tNear;
+    return ok;
 }
-
-// entry distance of the slab test above without the early outs (same operations, same bits)
-RT_DEV float bvh_near(V3 p, V3 inv, float4 b0, float4 b1)
+RT_DEV bool bvh_box(bool exact, V3 p, V3 inv, float t_max, f4 b0, f4 b1, float &dist)
 {
-    float tNear = 0.0f;
-    tNear = std_max(tNear, std_min((b0.x - p.x) * inv.x, (b0.w - p.x) * inv.x));
-    tNear = std_max(tNear, std_min((b0.y - p.y) * inv.y, (b1.x - p.y) * inv.y));
-    tNear = std_max(tNear, std_min((b0.z - p.z) * inv.z, (b1.y - p.z) * inv.z));
-    return tNear;
+    if (__builtin_expect(exact, 0)) return bvh_box_t<true>(p, inv, t_max, b0, b1, dist);
+    return bvh_box_t<false>(p, inv, t_max, b0, b1, dist);
+}
+// entry distance alone (same operations, same bits)
+RT_DEV float bvh_near(bool exact, V3 p, V3 inv, f4 b0, f4 b1)
+{
+    float d;
+    (void)bvh_box(exact, p, inv, FLT_MAX, b0, b1, d);
+    return d;
+}
+RT_DEV bool needs_exact_slabs(V3 inv)
+{
+    return !(fabsf(inv.x) < INFINITY && fabsf(inv.y) < INFINITY && fabsf(inv.z) < INFINITY);
 }
 
 // one Moeller-Trumbore test (src/TriObj.cpp:46-74) up to, not including, the range test on t
-RT_DEV bool tri_test(const float4 *rec, Ray r, float &t, float &u, float &v, float &det, uint32_t &face)
+RT_DEV bool tri_test(GF4 rec, Ray r, float &t, float &u, float &v, float &det, uint32_t &face)
 {
     const float epsilon = 1e-6f;
-    const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+    const f4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
     const V3 v0 = mk(q0.x, q0.y, q0.z), v1 = mk(q0.w, q1.x, q1.y), v2 = mk(q1.z, q1.w, q2.x);
     face = __float_as_uint(q2.y);
     const V3 e1 = v1 - v0;
@@ -164,8 +191,6 @@ RT_DEV bool tri_test(const float4 *rec, Ray r, float &t, float &u, float &v, flo
     return true;
 }
 
-constexpr uint32_t kLeafBit = 0x80000000u;
-
 // TriObj::IntersectRay (src/TriObj.cpp:12-137) without the final attribute
 // interpolation: same node order, same pruning, same tie rules.
 template <bool COUNT>
@@ -174,20 +199,22 @@ RT_DEV bool mesh_closest(const DMesh &M, Ray r, LaneStack st, float &tOut, uint3
 {
     const float epsilon = 1e-6f;
     const V3 inv = mk(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+    const bool exact = needs_exact_slabs(inv);
+    const GF4 bvh = (GF4)M.bvh, tris = (GF4)M.tris;
     float closestT = FLT_MAX;
     int sp = 0;
     {
         float dist;
         tl.boxes(1);
-        if (!bvh_box(r.p, inv, closestT, M.bvh[2], M.bvh[3], dist)) return false;
+        if (!bvh_box(exact, r.p, inv, closestT, bvh[2], bvh[3], dist)) return false;
         st.id[0] = 1; sp = 1;
     }
     bool hit = false;
     while (sp > 0) {
         --sp;
         const uint32_t id = st.id[sp * kStackStride];
-        const float4 n0 = M.bvh[id * 2], n1 = M.bvh[id * 2 + 1];
-        if (closestT < bvh_near(r.p, inv, n0, n1)) continue; // entered farther than the best hit so far
+        const f4 n0 = bvh[id * 2], n1 = bvh[id * 2 + 1];
+        if (closestT < bvh_near(exact, r.p, inv, n0, n1)) continue; // entered farther than the best hit so far
         const uint32_t data = __float_as_uint(n1.z);
         if (data & kLeafBit) {
             const uint32_t off = data & 0x0FFFFFFFu;
@@ -195,19 +222,19 @@ RT_DEV bool mesh_closest(const DMesh &M, Ray r, LaneStack st, float &tOut, uint3
             for (uint32_t i = 0; i < cnt; ++i) {
                 float t, u, v, det; uint32_t face;
                 tl.tris(1);
-                if (!tri_test(&M.tris[(off + i) * 3], r, t, u, v, det, face)) continue;
+                if (!tri_test(&tris[(off + i) * 3], r, t, u, v, det, face)) continue;
                 if (t <= epsilon || t > closestT) continue;
                 hit = true; closestT = t; detOut = det; uOut = u; vOut = v; faceOut = face;
             }
             continue;
         }
         const uint32_t c1 = data & 0x7FFFFFFFu, c2 = c1 + 1;
-        const float4 a0 = M.bvh[c1 * 2], a1 = M.bvh[c1 * 2 + 1], b0 = M.bvh[c2 * 2], b1 = M.bvh[c2 * 2 + 1];
+        const f4 a0 = bvh[c1 * 2], a1 = bvh[c1 * 2 + 1], b0 = bvh[c2 * 2], b1 = bvh[c2 * 2 + 1];
         float d1, d2;
         tl.boxes(2);
-        bool h1 = bvh_box(r.p, inv, closestT, a0, a1, d1);
+        bool h1 = bvh_box(exact, r.p, inv, closestT, a0, a1, d1);
         h1 = h1 && d1 < closestT;
-        bool h2 = bvh_box(r.p, inv, closestT, b0, b1, d2);
+        bool h2 = bvh_box(exact, r.p, inv, closestT, b0, b1, d2);
         h2 = h2 && d2 < closestT;
         if (!h1 && !h2) continue;
         if (h1 && h2) {
@@ -230,35 +257,37 @@ RT_DEV bool mesh_shadow(const DMesh &M, Ray r, float t_max, LaneStack st, Tally<
 {
     const float epsilon = 1e-6f;
     const V3 inv = mk(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+    const bool exact = needs_exact_slabs(inv);
+    const GF4 bvh = (GF4)M.bvh, tris = (GF4)M.tris;
     int sp = 0;
     {
         float dist;
         tl.boxes(1);
-        if (!bvh_box(r.p, inv, t_max, M.bvh[2], M.bvh[3], dist)) return false;
+        if (!bvh_box(exact, r.p, inv, t_max, bvh[2], bvh[3], dist)) return false;
         st.id[0] = 1; sp = 1;
     }
     while (sp > 0) {
         --sp;
         const uint32_t id = st.id[sp * kStackStride];
-        const uint32_t data = __float_as_uint(M.bvh[id * 2 + 1].z);
+        const uint32_t data = __float_as_uint(bvh[id * 2 + 1].z);
         if (data & kLeafBit) {
             const uint32_t off = data & 0x0FFFFFFFu;
             const uint32_t cnt = ((data >> 28) & 7u) + 1;
             for (uint32_t i = 0; i < cnt; ++i) {
                 float t, u, v, det; uint32_t face;
                 tl.tris(1);
-                if (!tri_test(&M.tris[(off + i) * 3], r, t, u, v, det, face)) continue;
+                if (!tri_test(&tris[(off + i) * 3], r, t, u, v, det, face)) continue;
                 if (t <= epsilon || t > t_max) continue;
                 return true;
             }
             continue;
         }
         const uint32_t c1 = data & 0x7FFFFFFFu, c2 = c1 + 1;
-        const float4 a0 = M.bvh[c1 * 2], a1 = M.bvh[c1 * 2 + 1], b0 = M.bvh[c2 * 2], b1 = M.bvh[c2 * 2 + 1];
+        const f4 a0 = bvh[c1 * 2], a1 = bvh[c1 * 2 + 1], b0 = bvh[c2 * 2], b1 = bvh[c2 * 2 + 1];
         float d1, d2;
         tl.boxes(2);
-        const bool h1 = bvh_box(r.p, inv, t_max, a0, a1, d1);
-        const bool h2 = bvh_box(r.p, inv, t_max, b0, b1, d2);
+        const bool h1 = bvh_box(exact, r.p, inv, t_max, a0, a1, d1);
+        const bool h2 = bvh_box(exact, r.p, inv, t_max, b0, b1, d2);
         if (!h1 && !h2) continue;
         if (h1 && h2) {
             const bool firstNear = d1 < d2;
@@ -385,12 +414,16 @@ RT_DEV void finish_hit(const DScene &S, Ray ray, Hit &h, bool want_uvw)
         h.uvw = h.p * 0.5f + mk(1.0f, 1.0f, 1.0f);
     } else {
         const DMesh &M = S.meshes[nd.mesh];
-        const uint32_t *nf = &M.fn[h.face * 3];
+        const GU32 fn = (GU32)M.fn;
+        const GF32 vn = (GF32)M.vn;
+        const uint32_t n0 = fn[h.face * 3], n1 = fn[h.face * 3 + 1], n2 = fn[h.face * 3 + 2];
         const float w = 1.0f - h.u - h.v;
-        h.n = normalize((ld3(&M.vn[nf[0] * 3]) * w + ld3(&M.vn[nf[1] * 3]) * h.u) + ld3(&M.vn[nf[2] * 3]) * h.v);
+        h.n = normalize((gld3(vn + n0 * 3) * w + gld3(vn + n1 * 3) * h.u) + gld3(vn + n2 * 3) * h.v);
         if (want_uvw) {
-            const uint32_t *tf = &M.ft[h.face * 3];
-            h.uvw = (ld3(&M.vt[tf[0] * 3]) * w + ld3(&M.vt[tf[1] * 3]) * h.u) + ld3(&M.vt[tf[2] * 3]) * h.v;
+            const GU32 ft = (GU32)M.ft;
+            const GF32 vt = (GF32)M.vt;
+            const uint32_t t0 = ft[h.face * 3], t1 = ft[h.face * 3 + 1], t2 = ft[h.face * 3 + 2];
+            h.uvw = (gld3(vt + t0 * 3) * w + gld3(vt + t1 * 3) * h.u) + gld3(vt + t2 * 3) * h.v;
         }
     }
     for (int k = depth; k >= 0; --k) {

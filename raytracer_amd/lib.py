@@ -12,7 +12,8 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librt_mi355x.so")
+# RT_LIB selects another build of the same library (kernel tuning experiments only)
+LIB_PATH = os.environ.get("RT_LIB") or os.path.join(_HERE, "librt_mi355x.so")
 
 # every symbol include/rt_mi355x.h declares
 SYMBOLS = (
