@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="mesh_1m_1080p_64spp", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--max-bounces", type=int, default=50, help="development only: the headline number uses 50")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -108,7 +109,8 @@ def main():
     ctx = lib.Context(local)
     ctx.upload(hs.desc)
     ctx.set_camera(hs.camera)
-    prm = abi.default_params(min_spp=spp, max_spp=spp, seed=7, tile_rank=rank, tile_world=world)
+    prm = abi.default_params(min_spp=spp, max_spp=spp, seed=7, tile_rank=rank, tile_world=world,
+                             max_bounces=args.max_bounces)
     fb = FrameBuffers(w, h, dev)
     gather = FrameGather(w, h, prm.tile_size, rank, world, dev)
     host_rgb = torch.empty((w * h, 3), dtype=torch.uint8).pin_memory()

@@ -35,10 +35,13 @@ struct PixelState {
 };
 
 static_assert(kBlock == (int)kStackStride, "stack[level][thread] layout assumes one block per stride");
-RT_DEV LaneStack lane_stack(uint32_t *lds)
+RT_DEV LaneStack lane_stack(uint32_t *lds, const DScene &S)
 {
     LaneStack st;
-    st.id = lds + threadIdx.x;
+    st.lds = reinterpret_cast<uint2 *>(lds) + threadIdx.x;
+    st.ovf = S.stack_overflow + ((size_t)blockIdx.x * kBlock + threadIdx.x);
+    st.lds_levels = (uint32_t)S.lds_levels;
+    st.ovf_stride = gridDim.x * kBlock;
     return st;
 }
 
@@ -111,7 +114,7 @@ __global__ __launch_bounds__(kBlock, RT_PATHS_MIN_WAVES) void k_paths(DScene S, 
                                                   unsigned long long *queue)
 {
     extern __shared__ uint32_t lds[];
-    const LaneStack st = lane_stack(lds);
+    const LaneStack st = lane_stack(lds, S);
     const uint32_t lane = threadIdx.x & 63u;
     PathTally pt;
     Tally<COUNT> tl;
@@ -247,64 +250,61 @@ __global__ __launch_bounds__(kBlock) void k_resolve(DFrame F, const int32_t *__r
     if (out.sample_count) out.sample_count[pix] = s.n;
 }
 
-// ---- batch queries ----
+// ---- batch queries: grid-stride loops, the grid is bounded by the host so that the
+// per-thread stack overflow area covers every thread ----
 __global__ __launch_bounds__(kBlock) void k_trace(DScene S, const float *__restrict__ rays6, int n, rt_hit *__restrict__ out)
 {
     extern __shared__ uint32_t lds[];
-    const LaneStack st = lane_stack(lds);
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    Ray r;
-    r.p = ld3(rays6 + (size_t)i * 6); r.d = ld3(rays6 + (size_t)i * 6 + 3);
-    Hit h;
-    Tally<false> tl;
-    const bool hit = trace_closest<false, kMaxSceneDepth - 1>(S, r, st, h, tl);
-    if (hit && h.node >= 0) finish_hit(S, r, h, true);
-    else { h.p = mk(0, 0, 0); h.n = mk(0, 0, 0); h.uvw = mk(0.5f, 0.5f, 0.5f); }
-    rt_hit o;
-    o.z = h.z;
-    o.p[0] = h.p.x; o.p[1] = h.p.y; o.p[2] = h.p.z;
-    o.n[0] = h.n.x; o.n[1] = h.n.y; o.n[2] = h.n.z;
-    o.uvw[0] = h.uvw.x; o.uvw[1] = h.uvw.y; o.uvw[2] = h.uvw.z;
-    o.node = hit ? h.node : -1;
-    o.front = h.front;
-    out[i] = o;
+    const LaneStack st = lane_stack(lds, S);
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        Ray r;
+        r.p = ld3(rays6 + (size_t)i * 6); r.d = ld3(rays6 + (size_t)i * 6 + 3);
+        Hit h;
+        Tally<false> tl;
+        const bool hit = trace_closest<false, kMaxSceneDepth - 1>(S, r, st, h, tl);
+        if (hit && h.node >= 0) finish_hit(S, r, h, true);
+        else { h.p = mk(0, 0, 0); h.n = mk(0, 0, 0); h.uvw = mk(0.5f, 0.5f, 0.5f); }
+        rt_hit o;
+        o.z = h.z;
+        o.p[0] = h.p.x; o.p[1] = h.p.y; o.p[2] = h.p.z;
+        o.n[0] = h.n.x; o.n[1] = h.n.y; o.n[2] = h.n.z;
+        o.uvw[0] = h.uvw.x; o.uvw[1] = h.uvw.y; o.uvw[2] = h.uvw.z;
+        o.node = hit ? h.node : -1;
+        o.front = h.front;
+        out[i] = o;
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void k_trace_shadow(DScene S, const float *__restrict__ rays6,
                                                          const float *__restrict__ t_max, int n, int32_t *__restrict__ out)
 {
     extern __shared__ uint32_t lds[];
-    const LaneStack st = lane_stack(lds);
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    Ray r;
-    r.p = ld3(rays6 + (size_t)i * 6); r.d = ld3(rays6 + (size_t)i * 6 + 3);
-    Tally<false> tl;
-    out[i] = trace_shadow<false, kMaxSceneDepth - 1>(S, r, t_max[i], st, tl) ? 1 : 0;
+    const LaneStack st = lane_stack(lds, S);
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        Ray r;
+        r.p = ld3(rays6 + (size_t)i * 6); r.d = ld3(rays6 + (size_t)i * 6 + 3);
+        Tally<false> tl;
+        out[i] = trace_shadow<false, kMaxSceneDepth - 1>(S, r, t_max[i], st, tl) ? 1 : 0;
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void k_trace_paths(DScene S, DFrame F, const float *__restrict__ rays6, int n,
                                                         float *__restrict__ radiance3, DCounters *ctr)
 {
     extern __shared__ uint32_t lds[];
-    const LaneStack st = lane_stack(lds);
-    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const LaneStack st = lane_stack(lds, S);
     PathTally pt;
     Tally<false> tl;
     uint32_t paths = 0;
-    if (i < n) {
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         Ray r;
         r.p = ld3(rays6 + (size_t)i * 6); r.d = ld3(rays6 + (size_t)i * 6 + 3);
-        Rng rng;
-        rng_set_sequence(rng, (uint64_t)i + 1, F.seed);
         PathState ps;
         path_begin(ps, r);
-        ps.rng = rng;
+        rng_set_sequence(ps.rng, (uint64_t)i + 1, F.seed);
         while (path_step<false, kMaxSceneDepth - 1>(S, F, ps, st, pt, tl, nullptr, nullptr)) {}
-        const V3 c = ps.result;
-        radiance3[(size_t)i * 3] = c.x; radiance3[(size_t)i * 3 + 1] = c.y; radiance3[(size_t)i * 3 + 2] = c.z;
-        paths = 1;
+        radiance3[(size_t)i * 3] = ps.result.x; radiance3[(size_t)i * 3 + 1] = ps.result.y; radiance3[(size_t)i * 3 + 2] = ps.result.z;
+        ++paths;
     }
     flush_counters<false>(ctr, pt, tl, paths);
 }

@@ -50,6 +50,8 @@ struct DScene {
     int32_t n_lights;
     float background[3];
     int32_t stack_levels; // BVH stack entries a lane may need (deepest mesh + 2), 0 without meshes
+    int32_t lds_levels;   // of which in LDS; the rest in stack_overflow
+    uint2 *stack_overflow; // [(stack_levels - lds_levels)][threads of the largest grid]
 };
 
 // Frame constants (camera + sampling), by value in the kernel arguments.

@@ -6,6 +6,12 @@
 #pragma once
 #include "trace.h"
 
+#ifdef RT_ABLATE_NATIVE_MATH // timing experiment only: hardware approximations, results change
+#define sinf __sinf
+#define cosf __cosf
+#define powf __powf
+#endif
+
 namespace rtd {
 
 constexpr float kPi = (float)3.141592653589793238462643383279502884197169; // cyCore.h:262

@@ -26,13 +26,33 @@ struct Hit {
     float u, v;
 };
 
-// Per-lane BVH stack in LDS, 4 bytes per entry (node id only): entry k of thread t
-// is at ids[k * kStackStride + t].  The entry distance the reference keeps next to the
-// id (src/TriObj.cpp:15,35-37) is recomputed from the node's bounds when it is popped;
-// it is a pure function of ray and bounds, so the value is the same.
+// Per-lane BVH stack.  An entry is what the reference keeps (src/TriObj.cpp:15,32-37):
+// the node and the distance at which the ray enters its box - except that the node
+// is kept as its data word (leaf range or first-child index) rather than its id, so
+// a popped entry leads straight to the children / triangles with one dependent
+// fetch instead of two.  The first `lds_levels` entries of a lane live in LDS as
+// entry[level][thread] (8-byte accesses of 32 consecutive lanes cover the 64 banks
+// exactly once, whatever level each lane is at); deeper entries, which are rare, go
+// to a global overflow array laid out the same way.
 constexpr uint32_t kStackStride = 256;
 struct LaneStack {
-    uint32_t *id; // &lds_ids[threadIdx.x]
+    uint2 *lds;          // &entries[threadIdx.x]
+    uint2 *ovf;          // &overflow[global thread id]
+    uint32_t lds_levels;
+    uint32_t ovf_stride; // threads in the grid
+    RT_DEV void push(int sp, uint32_t data, float dist) const
+    {
+        const uint2 e = make_uint2(data, __float_as_uint(dist));
+        if ((uint32_t)sp < lds_levels) lds[(uint32_t)sp * kStackStride] = e;
+        else ovf[(size_t)((uint32_t)sp - lds_levels) * ovf_stride] = e;
+    }
+    RT_DEV void pop(int sp, uint32_t &data, float &dist) const
+    {
+        uint2 e;
+        if ((uint32_t)sp < lds_levels) e = lds[(uint32_t)sp * kStackStride];
+        else e = ovf[(size_t)((uint32_t)sp - lds_levels) * ovf_stride];
+        data = e.x; dist = __uint_as_float(e.y);
+    }
 };
 
 template <bool COUNT> struct Tally {
@@ -169,10 +189,9 @@ RT_DEV bool needs_exact_slabs(V3 inv)
 }
 
 // one Moeller-Trumbore test (src/TriObj.cpp:46-74) up to, not including, the range test on t
-RT_DEV bool tri_test(GF4 rec, Ray r, float &t, float &u, float &v, float &det, uint32_t &face)
+RT_DEV bool tri_test(f4 q0, f4 q1, f4 q2, Ray r, float &t, float &u, float &v, float &det, uint32_t &face)
 {
     const float epsilon = 1e-6f;
-    const f4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
     const V3 v0 = mk(q0.x, q0.y, q0.z), v1 = mk(q0.w, q1.x, q1.y), v2 = mk(q1.z, q1.w, q2.x);
     face = __float_as_uint(q2.y);
     const V3 e1 = v1 - v0;
@@ -191,113 +210,95 @@ RT_DEV bool tri_test(GF4 rec, Ray r, float &t, float &u, float &v, float &det, u
     return true;
 }
 
-// TriObj::IntersectRay (src/TriObj.cpp:12-137) without the final attribute
-// interpolation: same node order, same pruning, same tie rules.
+// TriObj::IntersectRay / IntersectShadowRay (src/TriObj.cpp:12-229) without the final
+// attribute interpolation: same node order, same pruning, same tie rules.
+//   any_hit = false: closest hit; t_limit starts at FLT_MAX and shrinks with every hit
+//   any_hit = true : shadow ray; t_limit is the fixed t_max and the first hit ends the walk
+// The two forms of the reference differ only in that; in particular both push the
+// nearer child last, and for a shadow ray "entered before t_limit" holds for every
+// pushed node by construction, so the shared pruning tests never fire for it.
 template <bool COUNT>
-RT_DEV bool mesh_closest(const DMesh &M, Ray r, LaneStack st, float &tOut, uint32_t &faceOut, float &uOut,
-                         float &vOut, float &detOut, Tally<COUNT> &tl)
+RT_DEV bool mesh_traverse(const DMesh &M, Ray r, float t_limit, bool any_hit, LaneStack st, float &tOut,
+                          uint32_t &faceOut, float &uOut, float &vOut, float &detOut, Tally<COUNT> &tl)
 {
     const float epsilon = 1e-6f;
     const V3 inv = mk(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
     const bool exact = needs_exact_slabs(inv);
     const GF4 bvh = (GF4)M.bvh, tris = (GF4)M.tris;
-    float closestT = FLT_MAX;
     int sp = 0;
     {
+        const f4 r0 = bvh[2], r1 = bvh[3];
         float dist;
         tl.boxes(1);
-        if (!bvh_box(exact, r.p, inv, closestT, bvh[2], bvh[3], dist)) return false;
-        st.id[0] = 1; sp = 1;
+        if (!bvh_box(exact, r.p, inv, t_limit, r0, r1, dist)) return false;
+        st.push(0, __float_as_uint(r1.z), dist);
+        sp = 1;
     }
     bool hit = false;
     while (sp > 0) {
         --sp;
-        const uint32_t id = st.id[sp * kStackStride];
-        const f4 n0 = bvh[id * 2], n1 = bvh[id * 2 + 1];
-        if (closestT < bvh_near(exact, r.p, inv, n0, n1)) continue; // entered farther than the best hit so far
-        const uint32_t data = __float_as_uint(n1.z);
+        uint32_t data; float nodeT;
+        st.pop(sp, data, nodeT);
+        if (t_limit < nodeT) continue; // entered farther than the best hit so far
         if (data & kLeafBit) {
             const uint32_t off = data & 0x0FFFFFFFu;
             const uint32_t cnt = ((data >> 28) & 7u) + 1;
-            for (uint32_t i = 0; i < cnt; ++i) {
+            // two triangles per trip: their six loads are in flight together
+            for (uint32_t i = 0; i < cnt; i += 2) {
+                const GF4 ra = &tris[(off + i) * 3];
+                const bool two = i + 1 < cnt;
+                const GF4 rb = two ? ra + 3 : ra;
+                const f4 a0 = ra[0], a1 = ra[1], a2 = ra[2], b0 = rb[0], b1 = rb[1], b2 = rb[2];
                 float t, u, v, det; uint32_t face;
                 tl.tris(1);
-                if (!tri_test(&tris[(off + i) * 3], r, t, u, v, det, face)) continue;
-                if (t <= epsilon || t > closestT) continue;
-                hit = true; closestT = t; detOut = det; uOut = u; vOut = v; faceOut = face;
+                if (tri_test(a0, a1, a2, r, t, u, v, det, face) && !(t <= epsilon || t > t_limit)) {
+                    hit = true; detOut = det; uOut = u; vOut = v; faceOut = face;
+                    if (any_hit) { tOut = t; return true; }
+                    t_limit = t;
+                }
+                tl.tris(two ? 1 : 0);
+                if (two && tri_test(b0, b1, b2, r, t, u, v, det, face) && !(t <= epsilon || t > t_limit)) {
+                    hit = true; detOut = det; uOut = u; vOut = v; faceOut = face;
+                    if (any_hit) { tOut = t; return true; }
+                    t_limit = t;
+                }
             }
             continue;
         }
-        const uint32_t c1 = data & 0x7FFFFFFFu, c2 = c1 + 1;
-        const f4 a0 = bvh[c1 * 2], a1 = bvh[c1 * 2 + 1], b0 = bvh[c2 * 2], b1 = bvh[c2 * 2 + 1];
+        const uint32_t c1 = data & 0x7FFFFFFFu;
+        const f4 a0 = bvh[c1 * 2], a1 = bvh[c1 * 2 + 1], b0 = bvh[c1 * 2 + 2], b1 = bvh[c1 * 2 + 3];
         float d1, d2;
         tl.boxes(2);
-        bool h1 = bvh_box(exact, r.p, inv, closestT, a0, a1, d1);
-        h1 = h1 && d1 < closestT;
-        bool h2 = bvh_box(exact, r.p, inv, closestT, b0, b1, d2);
-        h2 = h2 && d2 < closestT;
-        if (!h1 && !h2) continue;
+        bool h1 = bvh_box(exact, r.p, inv, t_limit, a0, a1, d1);
+        h1 = h1 && d1 < t_limit;
+        bool h2 = bvh_box(exact, r.p, inv, t_limit, b0, b1, d2);
+        h2 = h2 && d2 < t_limit;
+        const uint32_t k1 = __float_as_uint(a1.z), k2 = __float_as_uint(b1.z);
         if (h1 && h2) {
             // nearer child on top of the stack; on a tie the second child is visited first
             const bool firstNear = d1 < d2;
-            st.id[sp * kStackStride] = firstNear ? c2 : c1; ++sp;
-            st.id[sp * kStackStride] = firstNear ? c1 : c2; ++sp;
-            continue;
+            st.push(sp, firstNear ? k2 : k1, firstNear ? d2 : d1); ++sp;
+            st.push(sp, firstNear ? k1 : k2, firstNear ? d1 : d2); ++sp;
+        } else if (h1 || h2) {
+            st.push(sp, h1 ? k1 : k2, h1 ? d1 : d2); ++sp;
         }
-        st.id[sp * kStackStride] = h1 ? c1 : c2; ++sp;
     }
-    tOut = closestT;
+    tOut = t_limit;
     return hit;
 }
 
-// TriObj::IntersectShadowRay (src/TriObj.cpp:139-229).  The answer is an
-// existence test, so it does not depend on the visiting order.
+template <bool COUNT>
+RT_DEV bool mesh_closest(const DMesh &M, Ray r, LaneStack st, float &tOut, uint32_t &faceOut, float &uOut,
+                         float &vOut, float &detOut, Tally<COUNT> &tl)
+{
+    return mesh_traverse<COUNT>(M, r, FLT_MAX, false, st, tOut, faceOut, uOut, vOut, detOut, tl);
+}
+
 template <bool COUNT>
 RT_DEV bool mesh_shadow(const DMesh &M, Ray r, float t_max, LaneStack st, Tally<COUNT> &tl)
 {
-    const float epsilon = 1e-6f;
-    const V3 inv = mk(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
-    const bool exact = needs_exact_slabs(inv);
-    const GF4 bvh = (GF4)M.bvh, tris = (GF4)M.tris;
-    int sp = 0;
-    {
-        float dist;
-        tl.boxes(1);
-        if (!bvh_box(exact, r.p, inv, t_max, bvh[2], bvh[3], dist)) return false;
-        st.id[0] = 1; sp = 1;
-    }
-    while (sp > 0) {
-        --sp;
-        const uint32_t id = st.id[sp * kStackStride];
-        const uint32_t data = __float_as_uint(bvh[id * 2 + 1].z);
-        if (data & kLeafBit) {
-            const uint32_t off = data & 0x0FFFFFFFu;
-            const uint32_t cnt = ((data >> 28) & 7u) + 1;
-            for (uint32_t i = 0; i < cnt; ++i) {
-                float t, u, v, det; uint32_t face;
-                tl.tris(1);
-                if (!tri_test(&tris[(off + i) * 3], r, t, u, v, det, face)) continue;
-                if (t <= epsilon || t > t_max) continue;
-                return true;
-            }
-            continue;
-        }
-        const uint32_t c1 = data & 0x7FFFFFFFu, c2 = c1 + 1;
-        const f4 a0 = bvh[c1 * 2], a1 = bvh[c1 * 2 + 1], b0 = bvh[c2 * 2], b1 = bvh[c2 * 2 + 1];
-        float d1, d2;
-        tl.boxes(2);
-        const bool h1 = bvh_box(exact, r.p, inv, t_max, a0, a1, d1);
-        const bool h2 = bvh_box(exact, r.p, inv, t_max, b0, b1, d2);
-        if (!h1 && !h2) continue;
-        if (h1 && h2) {
-            const bool firstNear = d1 < d2;
-            st.id[sp * kStackStride] = firstNear ? c2 : c1; ++sp;
-            st.id[sp * kStackStride] = firstNear ? c1 : c2; ++sp;
-            continue;
-        }
-        st.id[sp * kStackStride] = h1 ? c1 : c2; ++sp;
-    }
-    return false;
+    float t, u, v, det; uint32_t face;
+    return mesh_traverse<COUNT>(M, r, t_max, true, st, t, face, u, v, det, tl);
 }
 
 // per-level local rays, selected by the wave-uniform node depth.  Value selects

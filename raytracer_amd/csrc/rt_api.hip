@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -56,6 +57,9 @@ struct rt_ctx {
     rt_camera camera{};
     // frame
     DeviceBuf d_halton, d_active[2], d_next_count, d_state, d_sbuf, d_counters, d_queue;
+    DeviceBuf d_stack_ovf;
+    size_t ovf_threads = 0;
+    int lds_levels_max = 13;
     int n_cu = 256;
     int ray_levels = 1; // hierarchy levels that have children
     DeviceBuf d_rgb, d_z, d_cnt, d_id, d_lin; // internal planes when the caller wants host output
@@ -150,7 +154,7 @@ const void *paths_kernel(bool counting, int ray_levels)
     return counting ? (const void *)k_paths<true, 5> : (const void *)k_paths<false, 5>;
 }
 
-size_t stack_lds_bytes(const DScene &S) { return (size_t)S.stack_levels * kBlock * 4; }
+size_t stack_lds_bytes(const DScene &S) { return (size_t)S.lds_levels * kBlock * 8; }
 
 } // namespace
 
@@ -191,6 +195,7 @@ int rt_init(int device, rt_ctx **out)
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
     ctx->n_cu = prop.multiProcessorCount;
+    if (const char *e2 = getenv("RT_LDS_LEVELS")) ctx->lds_levels_max = std::max(1, std::min(64, atoi(e2))); // tuning knob
     if ((e = ctx->d_queue.reserve(sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
     *out = ctx;
     return RT_OK;
@@ -323,8 +328,14 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc)
     }
     DScene S{};
     S.stack_levels = max_mesh_depth < 0 ? 0 : max_mesh_depth + 2;
-    if (stack_lds_bytes(S) > 160 * 1024)
-        return ctx->fail(RT_ERR_UNSUPPORTED, "BVH depth %d needs more LDS stack than a workgroup has", max_mesh_depth);
+    // LDS holds the first levels of every lane's stack (26 KiB per 256 threads lets six
+    // workgroups share a CU's 160 KiB); deeper entries spill to a global array sized
+    // for the largest grid any entry point launches
+    S.lds_levels = std::min(S.stack_levels, ctx->lds_levels_max);
+    const size_t ovf_levels = (size_t)(S.stack_levels - S.lds_levels);
+    ctx->ovf_threads = (size_t)ctx->n_cu * 8 * kBlock;
+    HIP_TRY(ctx, ctx->d_stack_ovf.reserve(std::max<size_t>(1, ovf_levels) * ctx->ovf_threads * sizeof(uint2)));
+    S.stack_overflow = ctx->d_stack_ovf.as<uint2>();
 
     HIP_TRY(ctx, ctx->d_nodes.reserve(sizeof(DNode) * nn));
     HIP_TRY(ctx, hipMemcpy(ctx->d_nodes.p, nodes.data(), sizeof(DNode) * nn, hipMemcpyHostToDevice));
@@ -509,6 +520,12 @@ int rt_render(rt_ctx *ctx, const rt_render_params *prm, rt_frame_out *out)
 }
 
 // ---- batch queries ----
+static dim3 batch_grid(const rt_ctx *ctx, int n)
+{
+    const size_t want = ((size_t)n + kBlock - 1) / kBlock;
+    return dim3((unsigned)std::max<size_t>(1, std::min(want, ctx->ovf_threads / kBlock)));
+}
+
 static int batch_common(rt_ctx *ctx, const float *rays6, int n)
 {
     if (!ctx) return RT_ERR_INVALID;
@@ -527,7 +544,7 @@ int rt_trace(rt_ctx *ctx, const float *rays6, int n, rt_hit *out)
     HIP_TRY(ctx, ctx->d_q_in.reserve((size_t)n * 24));
     HIP_TRY(ctx, ctx->d_q_out.reserve((size_t)n * sizeof(rt_hit)));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_q_in.p, rays6, (size_t)n * 24, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_trace, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), stack_lds_bytes(ctx->scene), s, ctx->scene,
+    hipLaunchKernelGGL(k_trace, batch_grid(ctx, n), dim3(kBlock), stack_lds_bytes(ctx->scene), s, ctx->scene,
                        ctx->d_q_in.as<float>(), n, ctx->d_q_out.as<rt_hit>());
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(out, ctx->d_q_out.p, (size_t)n * sizeof(rt_hit), hipMemcpyDeviceToHost, s));
@@ -547,7 +564,7 @@ int rt_trace_shadow(rt_ctx *ctx, const float *rays6, const float *t_max, int n, 
     HIP_TRY(ctx, ctx->d_q_out.reserve((size_t)n * 4));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_q_in.p, rays6, (size_t)n * 24, hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_q_aux.p, t_max, (size_t)n * 4, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_trace_shadow, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), stack_lds_bytes(ctx->scene), s, ctx->scene,
+    hipLaunchKernelGGL(k_trace_shadow, batch_grid(ctx, n), dim3(kBlock), stack_lds_bytes(ctx->scene), s, ctx->scene,
                        ctx->d_q_in.as<float>(), ctx->d_q_aux.as<float>(), n, ctx->d_q_out.as<int32_t>());
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(occluded, ctx->d_q_out.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
@@ -570,7 +587,7 @@ int rt_trace_paths(rt_ctx *ctx, const float *rays6, int n, uint64_t seed, const 
     HIP_TRY(ctx, ctx->d_q_out.reserve((size_t)n * 12));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_q_in.p, rays6, (size_t)n * 24, hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters.p, 0, sizeof(DCounters), s));
-    hipLaunchKernelGGL(k_trace_paths, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), stack_lds_bytes(ctx->scene), s, ctx->scene, F,
+    hipLaunchKernelGGL(k_trace_paths, batch_grid(ctx, n), dim3(kBlock), stack_lds_bytes(ctx->scene), s, ctx->scene, F,
                        ctx->d_q_in.as<float>(), n, ctx->d_q_out.as<float>(), ctx->d_counters.as<DCounters>());
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(radiance3, ctx->d_q_out.p, (size_t)n * 12, hipMemcpyDeviceToHost, s));
