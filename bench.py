@@ -177,8 +177,11 @@ def main():
                          "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
                          "kernel": "k_paths", "avg_launch_ms": avg_launch_s * 1e3,
                          "algorithmic_gflop_per_launch": flops_launch / 1e9,
+                         "box_tests_per_frame": int(stats[3].item()), "tri_tests_per_frame": int(stats[4].item()),
                          "note": "rank 0's launch; algorithmic flops from the kernels' own ray/box/triangle counters"},
         }
+        if any(c.phase_cycles):
+            out["phase_cycles"] = list(c.phase_cycles)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(hs, w, h, spp)
         print(json.dumps(out))

@@ -180,6 +180,7 @@ typedef struct rt_counters {
     double kernel_ms;       /* GPU time of the last rt_render, HIP events on the render stream */
     double trace_kernel_ms; /* of which: the path-tracing kernel(s) */
     uint32_t trace_launches;
+    uint64_t phase_cycles[8]; /* diagnostic builds only (RT_PROFILE_PHASES): wave clock cycles per kernel phase */
 } rt_counters;
 
 /* ---- context ---- */

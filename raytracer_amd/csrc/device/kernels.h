@@ -63,6 +63,9 @@ RT_DEV void flush_counters(DCounters *ctr, const PathTally &pt, const Tally<COUN
         atomicAdd(&ctr->shadow, (unsigned long long)s);
         atomicAdd(&ctr->paths, (unsigned long long)p);
         if (COUNT) { atomicAdd(&ctr->box_tests, (unsigned long long)b); atomicAdd(&ctr->tri_tests, (unsigned long long)t); }
+#ifdef RT_PROFILE_PHASES
+        for (int i = 0; i < 8; ++i) atomicAdd(&ctr->phase[i], pt.ph[i]); // lane 0's clocks stand for the wave
+#endif
     }
 }
 
@@ -132,6 +135,7 @@ __global__ __launch_bounds__(kBlock, RT_PATHS_MIN_WAVES) void k_paths(DScene S, 
     ps.rng.state = 0; ps.rng.inc = 1;
 
     for (;;) {
+        pt.tick();
         const uint64_t need = __ballot(!alive);
         if (need != 0) {
             if (chunk_next >= chunk_end && !exhausted) {
@@ -174,6 +178,7 @@ __global__ __launch_bounds__(kBlock, RT_PATHS_MIN_WAVES) void k_paths(DScene S, 
             if (exhausted) break; // every wave gets here: the queue only grows
             continue;
         }
+        pt.tock(4);
         if (alive) {
             if (!path_step<COUNT, LEVELS>(S, F, ps, st, pt, tl, &fz, &fid)) {
                 if (k == 0) {

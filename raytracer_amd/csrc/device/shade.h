@@ -191,6 +191,14 @@ RT_DEV float mtl_pdf(const rt_material &m, const Surface &s, V3 dir)
 
 struct PathTally {
     uint32_t closest = 0, shadow = 0;
+#ifdef RT_PROFILE_PHASES
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0;
+    RT_DEV void tick() { t0 = wall_clock64(); }
+    RT_DEV void tock(int i) { const unsigned long long t = wall_clock64(); ph[i] += t - t0; t0 = t; }
+#else
+    RT_DEV void tick() {}
+    RT_DEV void tock(int) {}
+#endif
 };
 
 // One camera path in flight.  A lane keeps this across bounces and swaps in a
@@ -227,7 +235,9 @@ RT_DEV bool path_step(const DScene &S, const DFrame &F, PathState &ps, LaneStack
     const Ray ray = ps.ray;
     Hit h;
     ++pt.closest;
+    pt.tick();
     const bool hit = trace_closest<COUNT, LEVELS>(S, ray, st, h, tl);
+    pt.tock(0);
     if (ps.bounce == 0 && first_z) { *first_z = h.z; *first_id = hit ? h.node : -1; }
     if (!hit) {
         ps.result = ps.result + ld3(S.background) * ps.throughput; // main.cpp:175-176
@@ -261,7 +271,10 @@ RT_DEV bool path_step(const DScene &S, const DFrame &F, PathState &ps, LaneStack
         sr.p = h.p + (normal * bias) * sign;
         sr.d = ne.dir;
         ++pt.shadow;
-        if (!trace_shadow<COUNT, LEVELS>(S, sr, ne.dist - bias, st, tl)) {
+        pt.tock(1);
+        const bool occluded = trace_shadow<COUNT, LEVELS>(S, sr, ne.dist - bias, st, tl);
+        pt.tock(2);
+        if (!occluded) {
             const float cosS = std_max(0.0f, dot(normal, sr.d));
             if (cosS > 0.0f && ne.prob > 0.0f) {
                 const float mp = mtl_pdf(mtl, s, ne.dir);
@@ -285,6 +298,7 @@ RT_DEV bool path_step(const DScene &S, const DFrame &F, PathState &ps, LaneStack
     ps.ray.p = h.p + (normal * bias) * sign;
     ps.throughput = ps.throughput * (in.mult / in.prob);
     ++ps.bounce;
+    pt.tock(3);
     return true;
 }
 

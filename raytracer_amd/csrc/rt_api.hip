@@ -1,6 +1,6 @@
 // C ABI of the GPU backend: context, scene upload, frame rendering, batch queries.
 // Host-side control only; the arithmetic lives in device/*.h.
-#include "device/kernels.h"
+#include "device/wavefront.h"
 #include "rt_mi355x.h"
 
 #include <algorithm>
@@ -58,6 +58,11 @@ struct rt_ctx {
     // frame
     DeviceBuf d_halton, d_active[2], d_next_count, d_state, d_sbuf, d_counters, d_queue;
     DeviceBuf d_stack_ovf;
+    // wavefront pipeline: path pool, ray queue, counters {count, alive, pad, pad, head(u64), item(u64)}
+    DeviceBuf d_pool, d_wq_rays, d_wq_ctr;
+    uint32_t pool_slots = 0;
+    uint32_t pool_max = 1u << 22;
+    bool use_wavefront = false;
     size_t ovf_threads = 0;
     int lds_levels_max = 13;
     int n_cu = 256;
@@ -131,7 +136,7 @@ int validate_params(rt_ctx *ctx, const rt_render_params *p)
     if (!p) return ctx->fail(RT_ERR_INVALID, "null render params");
     if (p->mode != RT_MODE_PATH) return ctx->fail(RT_ERR_UNSUPPORTED, "unknown render mode %d", p->mode);
     if (p->min_spp < 1 || p->max_spp < p->min_spp) return ctx->fail(RT_ERR_INVALID, "need 1 <= min_spp <= max_spp");
-    if (p->max_bounces < 0) return ctx->fail(RT_ERR_INVALID, "max_bounces < 0");
+    if (p->max_bounces < 0 || p->max_bounces > 65535) return ctx->fail(RT_ERR_INVALID, "max_bounces must be 0..65535");
     if (p->halton_period < 1 || p->halton_period > 64) return ctx->fail(RT_ERR_INVALID, "halton_period must be 1..64");
     if (p->tile_size < 1) return ctx->fail(RT_ERR_INVALID, "tile_size < 1");
     if (p->tile_world < 1 || p->tile_rank < 0 || p->tile_rank >= p->tile_world)
@@ -154,9 +159,71 @@ const void *paths_kernel(bool counting, int ray_levels)
     return counting ? (const void *)k_paths<true, 5> : (const void *)k_paths<false, 5>;
 }
 
+const void *wf_trace_kernel(bool counting, int ray_levels)
+{
+    if (ray_levels <= 1) return counting ? (const void *)k_wf_trace<true, 1> : (const void *)k_wf_trace<false, 1>;
+    if (ray_levels == 2) return counting ? (const void *)k_wf_trace<true, 2> : (const void *)k_wf_trace<false, 2>;
+    return counting ? (const void *)k_wf_trace<true, 5> : (const void *)k_wf_trace<false, 5>;
+}
+
 size_t stack_lds_bytes(const DScene &S) { return (size_t)S.lds_levels * kBlock * 8; }
 
 } // namespace
+
+// One launch range through the wavefront pipeline: alternate k_wf_logic (shade, emit
+// rays, refill slots) and k_wf_trace (drain the ray queue) until no slot holds a path.
+static int render_wavefront(rt_ctx *ctx, const DFrame &F, const int32_t *act, uint64_t items, int k0, int nk,
+                            const FramePlanes &planes, size_t lds)
+{
+    hipStream_t s = ctx->stream;
+    const uint32_t slots = (uint32_t)std::min<uint64_t>(ctx->pool_max, (items + kBlock - 1) / kBlock * kBlock);
+    // pool arrays, 256-byte aligned sub-allocations of one buffer
+    const size_t sizes[12] = {16, 16, 16, 16, 8, 16, 16, 8, 16, 16, 16, 4};
+    size_t offs[12], total = 0;
+    for (int i = 0; i < 12; ++i) { offs[i] = total; total += ((size_t)slots * sizes[i] + 255) / 256 * 256; }
+    HIP_TRY(ctx, ctx->d_pool.reserve(total));
+    HIP_TRY(ctx, ctx->d_wq_rays.reserve((size_t)slots * 2 * sizeof(uint32_t)));
+    HIP_TRY(ctx, ctx->d_wq_ctr.reserve(64));
+    char *base = ctx->d_pool.as<char>();
+    WfPool P{};
+    P.ray_o = (float4 *)(base + offs[0]); P.ray_d = (float4 *)(base + offs[1]); P.thr = (float4 *)(base + offs[2]);
+    P.res = (float4 *)(base + offs[3]); P.rng = (uint2 *)(base + offs[4]); P.meta = (uint4 *)(base + offs[5]);
+    P.hit = (float4 *)(base + offs[6]); P.hit_uv = (float2 *)(base + offs[7]); P.sh_o = (float4 *)(base + offs[8]);
+    P.sh_d = (float4 *)(base + offs[9]); P.contrib = (float4 *)(base + offs[10]); P.vis = (uint32_t *)(base + offs[11]);
+    P.n_slots = slots;
+    char *cb = ctx->d_wq_ctr.as<char>();
+    WfQueue Q{};
+    Q.rays = ctx->d_wq_rays.as<uint32_t>();
+    Q.count = (uint32_t *)cb; Q.alive = (uint32_t *)(cb + 4);
+    Q.head = (unsigned long long *)(cb + 16); Q.item = (unsigned long long *)(cb + 24);
+
+    const void *fn = wf_trace_kernel(ctx->counting, ctx->ray_levels);
+    int per_cu = 1;
+    HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kBlock, lds));
+    per_cu = std::max(1, std::min(per_cu, 8));
+    const dim3 trace_grid((unsigned)(ctx->n_cu * per_cu));
+    const dim3 logic_grid(slots / kBlock);
+
+    HIP_TRY(ctx, hipMemsetAsync(cb, 0, 32, s));
+    DScene a_scene = ctx->scene;
+    DCounters *a_ctr = ctx->d_counters.as<DCounters>();
+    void *targs[] = {&a_scene, &P, &Q, &a_ctr};
+    int first = 1;
+    for (uint32_t iter = 0;; ++iter) {
+        HIP_TRY(ctx, hipMemsetAsync(cb, 0, 24, s)); // count, alive, head; the item counter runs on
+        hipLaunchKernelGGL(k_wf_logic, logic_grid, dim3(kBlock), 0, s, ctx->scene, F, ctx->d_halton.as<float>(), act, items, k0, nk,
+                           ctx->d_sbuf.as<float4>(), planes, P, Q, a_ctr, first);
+        HIP_TRY(ctx, hipGetLastError());
+        first = 0;
+        HIP_TRY(ctx, hipLaunchKernel(fn, trace_grid, dim3(kBlock), targs, lds, s));
+        uint32_t h[2] = {0, 0};
+        HIP_TRY(ctx, hipMemcpyAsync(h, cb, sizeof h, hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipStreamSynchronize(s));
+        if (h[1] == 0) break; // no slot holds a path any more
+        if (iter > (1u << 24)) return ctx->fail(RT_ERR_HIP, "wavefront loop did not terminate");
+    }
+    return RT_OK;
+}
 
 extern "C" {
 
@@ -190,11 +257,15 @@ int rt_init(int device, rt_ctx **out)
     // per-lane BVH stacks may need more than the default 64 KiB of LDS per workgroup
     for (const void *k : {(const void *)k_paths<false, 1>, (const void *)k_paths<false, 2>, (const void *)k_paths<false, 5>,
                           (const void *)k_paths<true, 1>, (const void *)k_paths<true, 2>, (const void *)k_paths<true, 5>,
+                          (const void *)k_wf_trace<false, 1>, (const void *)k_wf_trace<false, 2>, (const void *)k_wf_trace<false, 5>,
+                          (const void *)k_wf_trace<true, 1>, (const void *)k_wf_trace<true, 2>, (const void *)k_wf_trace<true, 5>,
                           (const void *)k_trace, (const void *)k_trace_shadow, (const void *)k_trace_paths})
         (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
     ctx->n_cu = prop.multiProcessorCount;
+    if (const char *e3 = getenv("RT_PIPELINE")) ctx->use_wavefront = strcmp(e3, "wave") == 0; // "wave" = ray-queue pipeline, default: one path per lane
+    if (const char *e4 = getenv("RT_POOL")) ctx->pool_max = (uint32_t)std::max(256, atoi(e4));
     if (const char *e2 = getenv("RT_LDS_LEVELS")) ctx->lds_levels_max = std::max(1, std::min(64, atoi(e2))); // tuning knob
     if ((e = ctx->d_queue.reserve(sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
     *out = ctx;
@@ -449,6 +520,10 @@ int rt_render(rt_ctx *ctx, const rt_render_params *prm, rt_frame_out *out)
             const uint32_t cnt = std::min(chunk_px, n_active - first);
             const uint64_t items = (uint64_t)cnt * nk;
             const int32_t *act = ctx->d_active[cur].as<int32_t>() + first;
+            HIP_TRY(ctx, hipEventRecord(ctx->evk0, s));
+            if (ctx->use_wavefront) {
+                if (int rc = render_wavefront(ctx, F, act, items, k0, nk, P, lds)) return rc;
+            } else {
             // persistent launch: as many workgroups as the chip holds at once (more would only queue up)
             const void *fn = paths_kernel(ctx->counting, ctx->ray_levels);
             int per_cu = 1;
@@ -457,7 +532,6 @@ int rt_render(rt_ctx *ctx, const rt_render_params *prm, rt_frame_out *out)
             const uint64_t want_blocks = (items + kBlock - 1) / kBlock;
             const dim3 grid((unsigned)std::min<uint64_t>(want_blocks, (uint64_t)ctx->n_cu * per_cu));
             HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue.p, 0, sizeof(unsigned long long), s));
-            HIP_TRY(ctx, hipEventRecord(ctx->evk0, s));
             {
                 DScene a_scene = ctx->scene;
                 const float *a_hal = ctx->d_halton.as<float>();
@@ -468,6 +542,7 @@ int rt_render(rt_ctx *ctx, const rt_render_params *prm, rt_frame_out *out)
                 unsigned long long *a_queue = ctx->d_queue.as<unsigned long long>();
                 void *args[] = {&a_scene, &F, &a_hal, &act, &a_items, &a_k0, &a_nk, &a_sbuf, &P, &a_ctr, &a_queue};
                 HIP_TRY(ctx, hipLaunchKernel(fn, grid, dim3(kBlock), args, lds, s));
+            }
             }
             HIP_TRY(ctx, hipGetLastError());
             HIP_TRY(ctx, hipEventRecord(ctx->evk1, s));
@@ -515,6 +590,7 @@ int rt_render(rt_ctx *ctx, const rt_render_params *prm, rt_frame_out *out)
     rt_counters &c = ctx->counters;
     c.closest_rays = dc.closest; c.shadow_rays = dc.shadow; c.camera_paths = dc.paths;
     c.box_tests = dc.box_tests; c.tri_tests = dc.tri_tests;
+    for (int i = 0; i < 8; ++i) c.phase_cycles[i] = dc.phase[i];
     c.kernel_ms = ms; c.trace_kernel_ms = trace_ms; c.trace_launches = launches;
     return RT_OK;
 }

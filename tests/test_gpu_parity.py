@@ -130,6 +130,33 @@ def test_mesh_scene_vs_oracle_with_counters(ctx):
     assert abs(int(c.tri_tests) - int(cpu.stats.tri_tests)) <= 5e-3 * cpu.stats.tri_tests
 
 
+def test_wavefront_and_megakernel_pipelines_agree(monkeypatch):
+    """The ray-queue (wavefront) pipeline and the one-path-per-lane megakernel run the same
+    per-path arithmetic: every output plane and the ray counts must be identical."""
+    ctxs = {}
+    for mode in ("mega", "wave"):
+        monkeypatch.setenv("RT_PIPELINE", mode)
+        ctxs[mode] = lib.Context(0)
+    monkeypatch.delenv("RT_PIPELINE")
+    try:
+        for name, (w, h, mn, mx) in {"scene_a": (200, 120, 6, 6), "scene_mesh": (160, 90, 3, 20),
+                                      "image_nested_96x54_s8": (96, 54, 4, 4)}.items():
+            s = O.scene_from_golden(O.load_golden(name))
+            prm = abi.default_params(seed=17, min_spp=mn, max_spp=mx, delta_max=0.02)
+            frames, counts = {}, {}
+            for mode, c in ctxs.items():
+                frames[mode] = render_gpu(c, s, prm, w, h)
+                k = c.counters()
+                counts[mode] = (k.closest_rays, k.shadow_rays, k.camera_paths)
+            for plane in ("rgb", "z", "sample_count", "object_id"):
+                assert np.array_equal(getattr(frames["mega"], plane), getattr(frames["wave"], plane)), (name, plane)
+            assert np.array_equal(bits(frames["mega"].linear), bits(frames["wave"].linear)), name
+            assert counts["mega"] == counts["wave"], name
+    finally:
+        for c in ctxs.values():
+            c.close()
+
+
 def test_edge_cases(ctx):
     s = O.scene_from_golden(O.load_golden("scene_a"))
     # image smaller than a tile, odd sizes, one sample, no bounces
