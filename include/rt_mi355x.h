@@ -180,7 +180,7 @@ typedef struct rt_counters {
     double kernel_ms;       /* GPU time of the last rt_render, HIP events on the render stream */
     double trace_kernel_ms; /* of which: the path-tracing kernel(s) */
     uint32_t trace_launches;
-    uint64_t phase_cycles[8]; /* diagnostic builds only (RT_PROFILE_PHASES): wave clock cycles per kernel phase */
+    uint64_t phase_cycles[16]; /* diagnostic builds only (RT_PROFILE_PHASES): per kernel phase wave clocks [0..3], executions [4..7], active lanes [8..11] */
 } rt_counters;
 
 /* ---- context ---- */

@@ -64,7 +64,7 @@ RT_DEV void flush_counters(DCounters *ctr, const PathTally &pt, const Tally<COUN
         atomicAdd(&ctr->paths, (unsigned long long)p);
         if (COUNT) { atomicAdd(&ctr->box_tests, (unsigned long long)b); atomicAdd(&ctr->tri_tests, (unsigned long long)t); }
 #ifdef RT_PROFILE_PHASES
-        for (int i = 0; i < 8; ++i) atomicAdd(&ctr->phase[i], pt.ph[i]); // lane 0's clocks stand for the wave
+        for (int i = 0; i < 16; ++i) atomicAdd(&ctr->phase[i], pt.ph[i]); // lane 0's clocks stand for the wave
 #endif
     }
 }
@@ -102,9 +102,49 @@ RT_DEV Ray camera_ray(const DFrame &F, const float *halton, int i, int j, int k,
 }
 
 // Work queue of a launch: items [0, n_items) are handed out in chunks; a wave draws a
-// chunk with one atomic and feeds its lanes from it, so the queue word sees one
-// atomic per kChunk paths.
+// chunk with one atomic and feeds its lanes from it, so a queue word sees one atomic per
+// kChunk paths.  The range can be cut into RT_QUEUES contiguous parts with a queue word
+// each (on its own cache line): workgroups whose blockIdx agree modulo 8 share an XCD and
+// would start on the same part, keeping each L2 on one region of the image, and a wave
+// whose part is used up goes on to the next.  Measured on the 1M-triangle frame this
+// was no faster than one queue (all XCDs working through the same few tiles, 2.53 vs
+// 2.46 Grays/s), so one queue is the default.
+#ifndef RT_QUEUES
+#define RT_QUEUES 1
+#endif
 constexpr uint32_t kChunk = 512;
+constexpr uint32_t kQueues = RT_QUEUES;
+constexpr uint32_t kQueueStride = 16; // unsigned long longs between queue words (128 bytes)
+constexpr size_t kQueueBytes = kQueues * kQueueStride * sizeof(unsigned long long);
+
+struct WorkQueue {
+    unsigned long long *words;
+    uint64_t n_items, part; // part: items per queue, a multiple of kChunk
+    uint32_t q, tried;      // current part, parts found empty so far
+    uint64_t next = 0, end = 0;
+    bool exhausted = false;
+    RT_DEV WorkQueue(unsigned long long *w, uint64_t n) : words(w), n_items(n)
+    {
+        const uint64_t chunks = (n + kChunk - 1) / kChunk;
+        part = ((chunks + kQueues - 1) / kQueues) * kChunk;
+        q = blockIdx.x % kQueues;
+        tried = 0;
+    }
+    // wave-uniform: make [next, end) non-empty if any work is left anywhere
+    RT_DEV void refill(uint32_t lane)
+    {
+        while (next >= end && !exhausted) {
+            unsigned long long b = 0;
+            if (lane == 0) b = atomicAdd(&words[q * kQueueStride], (unsigned long long)kChunk);
+            b = __shfl(b, 0, 64);
+            const uint64_t lo = (uint64_t)q * part, hi = lo + part < n_items ? lo + part : n_items;
+            const uint64_t s = lo + b;
+            if (s < hi) { next = s; end = s + kChunk < hi ? s + kChunk : hi; }
+            else if (++tried >= kQueues) exhausted = true;
+            else q = (q + 1) % kQueues;
+        }
+    }
+};
 
 #ifndef RT_PATHS_MIN_WAVES
 #define RT_PATHS_MIN_WAVES 6 // waves per SIMD the register allocator must leave room for
@@ -123,9 +163,7 @@ __global__ __launch_bounds__(kBlock, RT_PATHS_MIN_WAVES) void k_paths(DScene S, 
     Tally<COUNT> tl;
     uint32_t paths = 0;
 
-    // wave-uniform queue window, per-lane path
-    uint64_t chunk_next = 0, chunk_end = 0;
-    bool exhausted = false;
+    WorkQueue wq(queue, n_items); // wave-uniform
     bool alive = false;
     uint64_t item = 0;
     int pix = 0, k = 0;
@@ -138,20 +176,13 @@ __global__ __launch_bounds__(kBlock, RT_PATHS_MIN_WAVES) void k_paths(DScene S, 
         pt.tick();
         const uint64_t need = __ballot(!alive);
         if (need != 0) {
-            if (chunk_next >= chunk_end && !exhausted) {
-                unsigned long long b = 0;
-                if (lane == 0) b = atomicAdd(queue, (unsigned long long)kChunk);
-                b = __shfl(b, 0, 64);
-                chunk_next = b < n_items ? b : n_items;
-                chunk_end = b + kChunk < n_items ? b + kChunk : n_items;
-                if (chunk_next >= chunk_end) exhausted = true;
-            }
-            const uint64_t avail = chunk_end - chunk_next;
+            wq.refill(lane);
+            const uint64_t avail = wq.end - wq.next;
             const uint32_t want = (uint32_t)__popcll(need);
             const uint32_t take = avail < want ? (uint32_t)avail : want;
             const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
             if (!alive && rank < take) {
-                item = chunk_next + rank;
+                item = wq.next + rank;
                 const uint32_t a = (uint32_t)(item / (uint32_t)nk);
                 k = k0 + (int)(item - (uint64_t)a * (uint32_t)nk);
                 pix = active[a];
@@ -172,10 +203,10 @@ __global__ __launch_bounds__(kBlock, RT_PATHS_MIN_WAVES) void k_paths(DScene S, 
                 alive = true;
                 ++paths;
             }
-            chunk_next += take;
+            wq.next += take;
         }
         if (!__any(alive)) {
-            if (exhausted) break; // every wave gets here: the queue only grows
+            if (wq.exhausted) break; // every wave gets here: the queue words only grow
             continue;
         }
         pt.tock(4);

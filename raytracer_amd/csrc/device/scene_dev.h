@@ -71,7 +71,7 @@ struct DFrame {
 
 struct DCounters {
     unsigned long long closest, shadow, paths, box_tests, tri_tests;
-    unsigned long long phase[8]; // diagnostic: wave clock cycles per phase (RT_PROFILE_PHASES builds)
+    unsigned long long phase[16]; // diagnostic: wave clock cycles per phase (RT_PROFILE_PHASES builds)
 };
 
 } // namespace rtd

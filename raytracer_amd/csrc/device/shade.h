@@ -192,12 +192,15 @@ RT_DEV float mtl_pdf(const rt_material &m, const Surface &s, V3 dir)
 struct PathTally {
     uint32_t closest = 0, shadow = 0;
 #ifdef RT_PROFILE_PHASES
-    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0;
+    unsigned long long ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0;
     RT_DEV void tick() { t0 = wall_clock64(); }
     RT_DEV void tock(int i) { const unsigned long long t = wall_clock64(); ph[i] += t - t0; t0 = t; }
+    // one execution of phase i with `lanes` active lanes, ended now
+    RT_DEV void ran(int i, uint64_t lanes) { tock(i); ph[4 + i] += 1; ph[8 + i] += (unsigned long long)__popcll(lanes); }
 #else
     RT_DEV void tick() {}
     RT_DEV void tock(int) {}
+    RT_DEV void ran(int, uint64_t) {}
 #endif
 };
 

@@ -1,6 +1,7 @@
 // C ABI of the GPU backend: context, scene upload, frame rendering, batch queries.
 // Host-side control only; the arithmetic lives in device/*.h.
 #include "device/wavefront.h"
+#include "device/pathsm.h"
 #include "rt_mi355x.h"
 
 #include <algorithm>
@@ -62,7 +63,8 @@ struct rt_ctx {
     DeviceBuf d_pool, d_wq_rays, d_wq_ctr;
     uint32_t pool_slots = 0;
     uint32_t pool_max = 1u << 22;
-    bool use_wavefront = false;
+    bool use_wavefront = false; // RT_PIPELINE=wave: separate logic / ray-queue kernels
+    bool use_lockstep = true;   // RT_PIPELINE=mega: one whole trace call per lane in lock-step (k_paths); sm: k_path_sm
     size_t ovf_threads = 0;
     int lds_levels_max = 13;
     int n_cu = 256;
@@ -152,8 +154,13 @@ void fill_frame(const rt_ctx *ctx, const rt_render_params *p, DFrame &F)
     F.max_bounces = p->max_bounces; F.bias = p->bias; F.halton_period = p->halton_period; F.seed = p->seed;
 }
 
-const void *paths_kernel(bool counting, int ray_levels)
+const void *paths_kernel(bool counting, int ray_levels, bool lockstep)
 {
+    if (!lockstep) {
+        if (ray_levels <= 1) return counting ? (const void *)k_path_sm<true, 1> : (const void *)k_path_sm<false, 1>;
+        if (ray_levels == 2) return counting ? (const void *)k_path_sm<true, 2> : (const void *)k_path_sm<false, 2>;
+        return counting ? (const void *)k_path_sm<true, 5> : (const void *)k_path_sm<false, 5>;
+    }
     if (ray_levels <= 1) return counting ? (const void *)k_paths<true, 1> : (const void *)k_paths<false, 1>;
     if (ray_levels == 2) return counting ? (const void *)k_paths<true, 2> : (const void *)k_paths<false, 2>;
     return counting ? (const void *)k_paths<true, 5> : (const void *)k_paths<false, 5>;
@@ -255,7 +262,9 @@ int rt_init(int device, rt_ctx **out)
     if ((e = ctx->d_counters.reserve(sizeof(DCounters))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = ctx->d_next_count.reserve(sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
     // per-lane BVH stacks may need more than the default 64 KiB of LDS per workgroup
-    for (const void *k : {(const void *)k_paths<false, 1>, (const void *)k_paths<false, 2>, (const void *)k_paths<false, 5>,
+    for (const void *k : {(const void *)k_path_sm<false, 1>, (const void *)k_path_sm<false, 2>, (const void *)k_path_sm<false, 5>,
+                          (const void *)k_path_sm<true, 1>, (const void *)k_path_sm<true, 2>, (const void *)k_path_sm<true, 5>,
+                          (const void *)k_paths<false, 1>, (const void *)k_paths<false, 2>, (const void *)k_paths<false, 5>,
                           (const void *)k_paths<true, 1>, (const void *)k_paths<true, 2>, (const void *)k_paths<true, 5>,
                           (const void *)k_wf_trace<false, 1>, (const void *)k_wf_trace<false, 2>, (const void *)k_wf_trace<false, 5>,
                           (const void *)k_wf_trace<true, 1>, (const void *)k_wf_trace<true, 2>, (const void *)k_wf_trace<true, 5>,
@@ -264,10 +273,13 @@ int rt_init(int device, rt_ctx **out)
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
     ctx->n_cu = prop.multiProcessorCount;
-    if (const char *e3 = getenv("RT_PIPELINE")) ctx->use_wavefront = strcmp(e3, "wave") == 0; // "wave" = ray-queue pipeline, default: one path per lane
+    if (const char *e3 = getenv("RT_PIPELINE")) {
+        ctx->use_wavefront = strcmp(e3, "wave") == 0;
+        ctx->use_lockstep = strcmp(e3, "sm") != 0;
+    }
     if (const char *e4 = getenv("RT_POOL")) ctx->pool_max = (uint32_t)std::max(256, atoi(e4));
     if (const char *e2 = getenv("RT_LDS_LEVELS")) ctx->lds_levels_max = std::max(1, std::min(64, atoi(e2))); // tuning knob
-    if ((e = ctx->d_queue.reserve(sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = ctx->d_queue.reserve(kQueueBytes)) != hipSuccess) return bail("hipMalloc", e);
     *out = ctx;
     return RT_OK;
 }
@@ -525,13 +537,13 @@ int rt_render(rt_ctx *ctx, const rt_render_params *prm, rt_frame_out *out)
                 if (int rc = render_wavefront(ctx, F, act, items, k0, nk, P, lds)) return rc;
             } else {
             // persistent launch: as many workgroups as the chip holds at once (more would only queue up)
-            const void *fn = paths_kernel(ctx->counting, ctx->ray_levels);
+            const void *fn = paths_kernel(ctx->counting, ctx->ray_levels, ctx->use_lockstep);
             int per_cu = 1;
             HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kBlock, lds));
             per_cu = std::max(1, std::min(per_cu, 8));
             const uint64_t want_blocks = (items + kBlock - 1) / kBlock;
             const dim3 grid((unsigned)std::min<uint64_t>(want_blocks, (uint64_t)ctx->n_cu * per_cu));
-            HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue.p, 0, sizeof(unsigned long long), s));
+            HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue.p, 0, kQueueBytes, s));
             {
                 DScene a_scene = ctx->scene;
                 const float *a_hal = ctx->d_halton.as<float>();
@@ -590,7 +602,7 @@ int rt_render(rt_ctx *ctx, const rt_render_params *prm, rt_frame_out *out)
     rt_counters &c = ctx->counters;
     c.closest_rays = dc.closest; c.shadow_rays = dc.shadow; c.camera_paths = dc.paths;
     c.box_tests = dc.box_tests; c.tri_tests = dc.tri_tests;
-    for (int i = 0; i < 8; ++i) c.phase_cycles[i] = dc.phase[i];
+    for (int i = 0; i < 16; ++i) c.phase_cycles[i] = dc.phase[i];
     c.kernel_ms = ms; c.trace_kernel_ms = trace_ms; c.trace_launches = launches;
     return RT_OK;
 }
