@@ -32,6 +32,11 @@ from raytracer_amd.dist import FrameBuffers, FrameGather  # noqa: E402
 # Moeller-Trumbore 60, shading of one path vertex ~300
 F_NODE, F_BACK, F_SPH, F_SPH_SH, F_PLANE, F_LIGHT, F_BOX, F_TRI, F_SHADE = 33, 48, 38, 33, 15, 44, 31, 60, 300
 PEAK_FP32_TFLOPS = 157.3  # MI355X vector FP32 peak (counts FMA as 2; this path runs un-fused for bit-exactness)
+PEAK_HBM_GBPS = 8000.0    # MI355X HBM3E
+# algorithmic bytes of the reference's data structures: a BVH node is 28 B per box test; a triangle test reads
+# 4 B element index + 12 B face + 36 B vertices; a shaded mesh hit reads 24 B of fn/ft and 72 B of vn/vt;
+# a finished pixel writes 3 + 4 + 4 + 4 B
+B_BOX, B_TRI, B_HIT, B_PIXEL = 28, 52, 96, 15
 
 WORKLOADS = {
     # name: (mesh quads x, y, width, height, spp)
@@ -57,6 +62,23 @@ def algorithmic_flops(desc, c):
     vertices = c.shadow_rays  # every shaded surface vertex sends exactly one shadow ray
     return (c.closest_rays * per_closest + c.shadow_rays * per_shadow + F_BOX * c.box_tests + F_TRI * c.tri_tests
             + vertices * (2 * F_BACK + F_SHADE))
+
+
+def algorithmic_bytes(c, pixels):
+    """Bytes one frame needs by the reference's own data layout, from the same counters."""
+    return B_BOX * c.box_tests + B_TRI * c.tri_tests + B_HIT * c.shadow_rays + B_PIXEL * pixels
+
+
+def measured_traffic(workload):
+    """Memory-side bytes per launch of the path kernel from the newest committed counter summary
+    (rocprofv3 --pmc passes of this same command, see tests/prof_round.sh); None if there is none."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_k_paths.json")), reverse=True):
+        d = json.load(open(f))
+        if d.get("workload") == workload:
+            m = d["memory_side"]
+            return (m["read_bytes"] + m["write_bytes"]) / d.get("launches_profiled", 1), os.path.basename(f)
+    return None, None
 
 
 def cpu_baseline(hs, w, h, spp, budget_s=12.0):
@@ -156,9 +178,13 @@ def main():
     rays_per_frame = float(stats[0] + stats[1])
 
     if rank == 0:
-        flops_launch = algorithmic_flops(hs.desc, counted) / max(1, counted.trace_launches)
+        n_launch = max(1, counted.trace_launches)
+        flops_launch = algorithmic_flops(hs.desc, counted) / n_launch
+        bytes_launch = algorithmic_bytes(counted, w * h // world) / n_launch
         avg_launch_s = kernel_ms / max(1, launches) / 1e3
-        achieved = flops_launch / avg_launch_s / 1e12
+        tflops = flops_launch / avg_launch_s / 1e12
+        gbps = bytes_launch / avg_launch_s / 1e9
+        traffic, traffic_src = measured_traffic(args.workload) if world == 1 and args.max_bounces == 50 else (None, None)
         out = {
             "metric": "Mrays/sec (whole node) at 1/2/4/8 MI355X, 1M-tri 1080p",
             "value": rays_per_frame * args.steps / dt / 1e6,
@@ -173,12 +199,15 @@ def main():
             "config": {"workload": args.workload, "triangles": ntri, "width": w, "height": h, "spp": spp,
                        "max_bounces": prm.max_bounces, "mode": "path", "parallelism": f"tiles/{world}",
                        "rays_per_frame": int(rays_per_frame), "camera_paths_per_frame": int(stats[2].item())},
-            "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
+            # the BVH walk is a dependent gather: memory is the roofline that bounds it; the FP32 side is reported beside it
+            "roofline": {"bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                         "frac": gbps / PEAK_HBM_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "k_paths", "avg_launch_ms": avg_launch_s * 1e3,
-                         "algorithmic_gflop_per_launch": flops_launch / 1e9,
+                         "algorithmic_gbyte_per_launch": bytes_launch / 1e9,
+                         "valu_fp32": {"achieved": tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                                       "frac": tflops / PEAK_FP32_TFLOPS, "algorithmic_gflop_per_launch": flops_launch / 1e9},
                          "box_tests_per_frame": int(stats[3].item()), "tri_tests_per_frame": int(stats[4].item()),
-                         "note": "rank 0's launch; algorithmic flops from the kernels' own ray/box/triangle counters"},
+                         "note": "rank 0's launch; algorithmic bytes and flops from the kernels' own ray/box/triangle counters"},
         }
         if any(c.phase_cycles):
             out["phase_cycles"] = list(c.phase_cycles)

@@ -1,0 +1,229 @@
+// Host-side C++ mirror of the reference's Renderer / RenderImage pair
+// (src/renderer.h:38-106, 205-238) on top of the C ABI of rt_mi355x.h: the same
+// method names, argument meaning and error behaviour (bool results, a line on
+// stderr, no exceptions), so code written against `renderer.LoadScene(...);
+// renderer.BeginRender(); ... GetRenderImage().GetPixels()` reads the same here.
+// Header-only; link with librt_mi355x.so.
+//
+// Differences a caller can see, all forced by where the work runs:
+//   * BeginRender() starts ONE host thread that drives the GPU for the whole frame
+//     (the reference starts hardware_concurrency() tile threads, src/main.cpp:599-606);
+//     pixels appear in the RenderImage when the frame is complete, and
+//     GetNumRenderedPixels() jumps from 0 to width*height at that moment.
+//   * StopRender() waits for the frame in flight (rt_render is one blocking call).
+//   * Rays and hits are plain structs of floats, not cyVector types.
+#ifndef RT_HIP_RENDERER_HPP
+#define RT_HIP_RENDERER_HPP
+
+#include "rt_mi355x.h"
+
+#include <atomic>
+#include <cfloat>
+#include <cstdint>
+#include <cstdio>
+#include <limits>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace rt {
+
+constexpr float BIGFLOAT = FLT_MAX; // src/scene.h: "no hit" depth
+
+struct Color24 { uint8_t r, g, b; };
+struct Ray { float p[3], dir[3]; };
+// the fields of the reference's HitInfo that its intersectors fill (src/scene.h:78-93)
+struct HitInfo {
+    float p[3] = {0, 0, 0};
+    float z = BIGFLOAT;
+    int node = -1;      // depth-first index of the node that was hit, -1 none
+    float N[3] = {0, 0, 0};
+    float uvw[3] = {0.5f, 0.5f, 0.5f};
+    bool front = true;
+    bool light = false; // a spherical light was the closest thing hit
+    int lightIndex = -1;
+};
+
+// src/renderer.h:38-106
+class RenderImage {
+    std::vector<Color24> img;
+    std::vector<float> zbuffer;
+    std::vector<uint8_t> zbufferImg;
+    std::vector<int> sampleCount;
+    std::vector<uint8_t> sampleCountImg;
+    std::vector<int32_t> objectId; // extra plane: node index of the first sample's camera-ray hit
+    int width = 0, height = 0;
+    std::atomic<int> numRenderedPixels{0};
+
+public:
+    void Init(int w, int h)
+    {
+        width = w; height = h;
+        const size_t size = (size_t)w * h;
+        img.assign(size, Color24{0, 0, 0});
+        zbuffer.assign(size, BIGFLOAT);
+        zbufferImg.assign(size, 0);
+        sampleCount.assign(size, 0);
+        sampleCountImg.assign(size, 0);
+        objectId.assign(size, -1);
+        ResetNumRenderedPixels();
+    }
+    int GetWidth() const { return width; }
+    int GetHeight() const { return height; }
+    Color24 *GetPixels() { return img.data(); }
+    float *GetZBuffer() { return zbuffer.data(); }
+    uint8_t *GetZBufferImage() { return zbufferImg.data(); }
+    int *GetSampleCount() { return sampleCount.data(); }
+    uint8_t *GetSampleCountImage() { return sampleCountImg.data(); }
+    int32_t *GetObjectIds() { return objectId.data(); }
+
+    void ResetNumRenderedPixels() { numRenderedPixels = 0; }
+    int GetNumRenderedPixels() const { return numRenderedPixels; }
+    bool IsRenderDone() const { return numRenderedPixels >= width * height; }
+    void IncrementNumRenderPixel(int n) { numRenderedPixels += n; }
+
+    void ComputeZBufferImage() { ComputeImage<float, true>(zbufferImg, zbuffer, BIGFLOAT); }
+    int ComputeSampleCountImage() { return ComputeImage<int, false>(sampleCountImg, sampleCount, 0); }
+
+private:
+    // min/max normalisation to 8 bits, skipping `skipv` (src/renderer.h:84-105)
+    template <typename T, bool invert> T ComputeImage(std::vector<uint8_t> &out, std::vector<T> &data, T skipv)
+    {
+        T vmin = std::numeric_limits<T>::max(), vmax = T(0);
+        for (const T &d : data) {
+            if (d == skipv) continue;
+            if (vmin > d) vmin = d;
+            if (vmax < d) vmax = d;
+        }
+        for (size_t i = 0; i < data.size(); ++i) {
+            if (data[i] == skipv) { out[i] = 0; continue; }
+            float f = float(data[i] - vmin) / float(vmax - vmin);
+            if (invert) f = 1 - f;
+            const int c = int(f * 255);
+            out[i] = c < 0 ? 0 : (c > 255 ? 255 : c);
+        }
+        return vmax;
+    }
+};
+
+class HipRenderer {
+    rt_ctx *ctx = nullptr;
+    rt_scene_host *host = nullptr;
+    rt_camera camera{};
+    RenderImage renderImage;
+    std::string sceneFile;
+    std::atomic<bool> isRendering{false};
+    std::thread worker;
+    rt_render_params params{};
+    int lastStatus = RT_OK;
+
+    bool Fail(const char *what, const char *msg) const
+    {
+        std::fprintf(stderr, "ERROR: %s: %s\n", what, msg ? msg : "");
+        return false;
+    }
+
+public:
+    // the constants the reference compiles in (src/main.cpp:93,107,164,220,273-274,369)
+    explicit HipRenderer(int device = 0)
+    {
+        params.mode = RT_MODE_PATH;
+        params.min_spp = 128; params.max_spp = 128; params.delta_max = 0.01f;
+        params.max_bounces = 50; params.bias = 0.002f; params.halton_period = 16;
+        params.tile_size = 16; params.tile_rank = 0; params.tile_world = 1; params.seed = 7;
+        if (rt_init(device, &ctx) != RT_OK) { Fail("rt_init", rt_last_error(nullptr)); ctx = nullptr; }
+    }
+    ~HipRenderer()
+    {
+        StopRender();
+        if (host) rt_scene_host_free(host);
+        if (ctx) rt_shutdown(ctx);
+    }
+    HipRenderer(const HipRenderer &) = delete;
+    HipRenderer &operator=(const HipRenderer &) = delete;
+
+    bool Ok() const { return ctx != nullptr; }
+    rt_render_params &Params() { return params; }   // spp, bounces, seed, tile shard
+    rt_camera &GetCamera() { return camera; }       // call SetCamera() after changing it
+    RenderImage &GetRenderImage() { return renderImage; }
+    std::string const &SceneFileName() const { return sceneFile; }
+    int LastStatus() const { return lastStatus; }
+
+    // Renderer::LoadScene (src/renderer.cpp, src/xmlload.cpp:35-78): parse, build, upload
+    bool LoadScene(char const *sceneFilename)
+    {
+        if (!ctx) return Fail("LoadScene", "no GPU context");
+        StopRender();
+        char err[512] = "";
+        rt_scene_host *h = nullptr;
+        if (rt_scene_load_xml(sceneFilename, &h, err, sizeof err) != RT_OK) return Fail(sceneFilename, err);
+        if (host) rt_scene_host_free(host);
+        host = h;
+        sceneFile = sceneFilename;
+        if ((lastStatus = rt_scene_upload(ctx, rt_scene_host_desc(host))) != RT_OK) return Fail("rt_scene_upload", rt_last_error(ctx));
+        camera = *rt_scene_host_camera(host);
+        return SetCamera();
+    }
+    bool SetCamera()
+    {
+        if (!ctx) return false;
+        if ((lastStatus = rt_camera_set(ctx, &camera)) != RT_OK) return Fail("rt_camera_set", rt_last_error(ctx));
+        renderImage.Init(camera.width, camera.height);
+        return true;
+    }
+
+    // One frame, blocking: what the tile threads of the reference produce together (src/main.cpp:271-385)
+    bool RenderFrame()
+    {
+        if (!ctx || !host) return Fail("RenderFrame", "no scene loaded");
+        renderImage.ResetNumRenderedPixels();
+        rt_frame_out out{};
+        out.rgb = (uint8_t *)renderImage.GetPixels();
+        out.z = renderImage.GetZBuffer();
+        out.sample_count = (int32_t *)renderImage.GetSampleCount();
+        out.object_id = renderImage.GetObjectIds();
+        if ((lastStatus = rt_render(ctx, &params, &out)) != RT_OK) return Fail("rt_render", rt_last_error(ctx));
+        renderImage.IncrementNumRenderPixel(renderImage.GetWidth() * renderImage.GetHeight());
+        return true;
+    }
+    // "Generates one or more rendering threads and begins rendering. Returns immediately." (src/renderer.h:228)
+    void BeginRender()
+    {
+        StopRender();
+        isRendering = true;
+        worker = std::thread([this] { RenderFrame(); isRendering = false; });
+    }
+    // "Stops the current rendering process. It should wait till rendering threads stop." (src/renderer.h:229)
+    void StopRender()
+    {
+        if (worker.joinable()) worker.join();
+        isRendering = false;
+    }
+    bool IsRendering() const { return isRendering; }
+
+    // Renderer::TraceRay / TraceShadowRay (src/main.cpp:115-125); both hit sides, as the reference's callers ask
+    bool TraceRay(Ray const &ray, HitInfo &hInfo) const
+    {
+        rt_hit h;
+        if (!ctx || rt_trace(ctx, ray.p, 1, &h) != RT_OK) return false; // p and dir are contiguous: 6 floats
+        if (h.node == -1) return false;
+        hInfo.z = h.z; hInfo.node = h.node; hInfo.front = h.front != 0;
+        hInfo.light = h.node < -1; hInfo.lightIndex = h.node < -1 ? -2 - h.node : -1;
+        for (int i = 0; i < 3; ++i) { hInfo.p[i] = h.p[i]; hInfo.N[i] = h.n[i]; hInfo.uvw[i] = h.uvw[i]; }
+        return true;
+    }
+    bool TraceShadowRay(Ray const &ray, float t_max) const
+    {
+        int32_t occluded = 0;
+        if (!ctx || rt_trace_shadow(ctx, ray.p, &t_max, 1, &occluded) != RT_OK) return false;
+        return occluded != 0;
+    }
+    // many rays at once: one launch instead of one per ray
+    bool TraceRays(const Ray *rays, int n, rt_hit *hits) const { return ctx && rt_trace(ctx, rays[0].p, n, hits) == RT_OK; }
+};
+
+static_assert(sizeof(Ray) == 6 * sizeof(float), "Ray must be six packed floats");
+static_assert(sizeof(Color24) == 3, "Color24 must be three bytes");
+
+} // namespace rt
+#endif

@@ -8,6 +8,6 @@ for v in "$@"; do
 import json,sys
 v=sys.argv[1]
 d=json.loads(open(f"gpurun_out/bench_{v}.log").read().strip().splitlines()[-1])
-print(f"{v:12s} {d['value']:9.1f} Mrays/s  {d['ms_per_step']:8.2f} ms/frame  launch {d['roofline']['avg_launch_ms']:8.2f} ms  rays/frame {d['config']['rays_per_frame']/1e6:.1f}M  frac {d['roofline']['frac']:.4f}")
+print(f"{v:12s} {d['value']:9.1f} Mrays/s  {d['ms_per_step']:8.2f} ms/frame  launch {d['roofline']['avg_launch_ms']:8.2f} ms  rays/frame {d['config']['rays_per_frame']/1e6:.1f}M  hbm frac {d['roofline']['frac']:.3f}")
 PY
 done

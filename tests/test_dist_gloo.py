@@ -1,0 +1,80 @@
+"""Multi-process frame assembly on CPU (gloo, world_size 2 and 3): every rank renders its
+tile shard - here with the CPU oracle standing in for the GPU - and FrameGather must
+leave the complete frame, identical to a single-process render, on every rank."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+
+W, H, SPP = 70, 45, 2  # not a multiple of the tile size: ragged right / bottom tiles
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, tile, out_dir):
+    import oraclelib as O
+    from raytracer_amd import abi
+    from raytracer_amd.dist import FrameBuffers, FrameGather, shard_pixels
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        s = O.scene_from_golden(O.load_golden("scene_a"))
+        prm = abi.default_params(seed=3, min_spp=SPP, max_spp=SPP, tile_size=tile, tile_rank=rank, tile_world=world)
+        part = O.render(s, prm, W, H, threads=1)
+        fb = FrameBuffers(W, H, torch.device("cpu"))
+        mine = torch.from_numpy(shard_pixels(W, H, tile, rank, world))
+        # only this rank's pixels are filled in; everything else is poisoned so a missing scatter shows
+        fb.rgb[:] = 0xAB
+        fb.z[:] = -1.0
+        fb.sample_count[:] = -7
+        fb.object_id[:] = -99
+        fb.rgb[mine] = torch.from_numpy(part.rgb.reshape(-1, 3))[mine]
+        fb.z[mine] = torch.from_numpy(part.z.reshape(-1))[mine]
+        fb.sample_count[mine] = torch.from_numpy(part.sample_count.reshape(-1))[mine]
+        fb.object_id[mine] = torch.from_numpy(part.object_id.reshape(-1))[mine]
+        FrameGather(W, H, tile, rank, world, torch.device("cpu"))(fb)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), rgb=fb.rgb.numpy(), z=fb.z.numpy(),
+                 n=fb.sample_count.numpy(), id=fb.object_id.numpy())
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,tile", [(2, 16), (3, 8)])
+def test_frame_gather_matches_single_process(tmp_path, world, tile):
+    import oraclelib as O
+    from raytracer_amd import abi
+    mp.spawn(_worker, args=(world, _free_port(), tile, str(tmp_path)), nprocs=world, join=True)
+    s = O.scene_from_golden(O.load_golden("scene_a"))
+    whole = O.render(s, abi.default_params(seed=3, min_spp=SPP, max_spp=SPP, tile_size=tile), W, H, threads=2)
+    for rank in range(world):
+        g = np.load(tmp_path / f"rank{rank}.npz")
+        assert np.array_equal(g["rgb"].reshape(H, W, 3), whole.rgb), f"rank {rank} rgb"
+        assert np.array_equal(g["z"].view(np.uint32), whole.z.reshape(-1).view(np.uint32)), f"rank {rank} z"
+        assert np.array_equal(g["n"], whole.sample_count.reshape(-1)), f"rank {rank} sample counts"
+        assert np.array_equal(g["id"], whole.object_id.reshape(-1)), f"rank {rank} ids"
+
+
+def test_shards_partition_the_frame():
+    from raytracer_amd.dist import shard_pixels
+    for (w, h, tile, world) in [(70, 45, 16, 2), (1920, 1080, 16, 8), (5, 3, 16, 4), (33, 33, 8, 3)]:
+        parts = [shard_pixels(w, h, tile, r, world) for r in range(world)]
+        allpx = np.concatenate(parts)
+        assert len(allpx) == w * h and np.array_equal(np.sort(allpx), np.arange(w * h))
+        sizes = [len(p) for p in parts]
+        tiles = -(-w // tile) * -(-h // tile)
+        if tiles >= world * 8:  # fine interleaving keeps the shards within a few tiles of each other
+            assert max(sizes) - min(sizes) <= 2 * tile * tile
