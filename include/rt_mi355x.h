@@ -205,6 +205,20 @@ int rt_trace_shadow(rt_ctx *ctx, const float *rays6, const float *t_max, int n, 
 int rt_trace_paths(rt_ctx *ctx, const float *rays6, int n, uint64_t seed,
                    const rt_render_params *params, float *radiance3);
 
+/* The same two queries answered by the persistent ray-list kernel (a lane that finishes a ray
+ * takes the next one at once): t_max == NULL asks for closest hits, otherwise for any hit
+ * below t_max[i]. Results are brief - no hit point, normal or uvw:
+ *   closest: t (FLT_MAX = none), node, face, front, u, v;   any-hit: node = 1 if occluded else 0.
+ * rt_get_counters().kernel_ms afterwards holds the kernel's own duration. */
+typedef struct rt_hit_brief {
+    float t;
+    int32_t node;
+    uint32_t face;
+    int32_t front;
+    float u, v;
+} rt_hit_brief;
+int rt_trace_brief(rt_ctx *ctx, const float *rays6, const float *t_max, int n, rt_hit_brief *out);
+
 int rt_get_counters(rt_ctx *ctx, rt_counters *out);
 /* box_tests / tri_tests are only counted while counting is on (a separately
  * compiled kernel variant; the default variant carries no per-test counters) */

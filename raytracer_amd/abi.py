@@ -78,6 +78,11 @@ class Hit(C.Structure):
                 ("node", C.c_int32), ("front", C.c_int32)]
 
 
+class HitBrief(C.Structure):
+    _fields_ = [("t", C.c_float), ("node", C.c_int32), ("face", C.c_uint32), ("front", C.c_int32),
+                ("u", C.c_float), ("v", C.c_float)]
+
+
 class Counters(C.Structure):
     _fields_ = [("closest_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("camera_paths", C.c_uint64),
                 ("box_tests", C.c_uint64), ("tri_tests", C.c_uint64), ("kernel_ms", C.c_double),
@@ -87,6 +92,8 @@ class Counters(C.Structure):
 HIT_DTYPE = np.dtype([("z", "<f4"), ("p", "<f4", 3), ("n", "<f4", 3), ("uvw", "<f4", 3),
                       ("node", "<i4"), ("front", "<i4")])
 assert HIT_DTYPE.itemsize == C.sizeof(Hit)
+HIT_BRIEF_DTYPE = np.dtype([("t", "<f4"), ("node", "<i4"), ("face", "<u4"), ("front", "<i4"), ("u", "<f4"), ("v", "<f4")])
+assert HIT_BRIEF_DTYPE.itemsize == C.sizeof(HitBrief)
 
 
 def default_params(**kw):

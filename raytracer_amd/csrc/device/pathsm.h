@@ -238,7 +238,7 @@ __global__ __launch_bounds__(kBlock, RT_SM_MIN_WAVES) void k_path_sm(DScene S, D
                         const DMesh &M = S.meshes[nd.mesh];
                         bvh = (GF4)M.bvh; tris = (GF4)M.tris;
                         inv = mk(1.0f / lr.d.x, 1.0f / lr.d.y, 1.0f / lr.d.z);
-                        exact = needs_exact_slabs(inv);
+                        exact = needs_exact_slabs(lr.p, inv);
                         t_limit = any_hit ? t_max : FLT_MAX;
                         m_hit = false;
                         const f4 r0 = bvh[2], r1 = bvh[3];

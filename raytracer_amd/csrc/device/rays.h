@@ -1,0 +1,261 @@
+// k_rays: closest-hit / any-hit queries for a list of rays, as a persistent kernel
+// with ray-level regeneration: a lane that finishes its ray takes the next one from
+// the list at once, so the lanes of a wave stay busy although rays need anything from
+// 3 to 60 BVH node visits (src/main.cpp:16-125, src/TriObj.cpp:12-229).  The lane
+// carries nothing but the ray and its walk, so the kernel runs at high occupancy.
+//
+// Where rays come from and where answers go is a policy (IO): a plain list for the batch
+// query entry point (RayListIO below), the path pool of the wavefront renderer (wavefront.h).
+//   bool fetch(e, o, d, any_hit, t_max)   entry e of the list; false = no ray there
+//   void put_closest(e, t, node, face, front, u, v)   t = FLT_MAX, node = -1: nothing hit
+//   void put_shadow(e, occluded)
+#pragma once
+#include "kernels.h"
+
+namespace rtd {
+
+// ray_o = origin xyz, w = t_max for an any-hit (shadow) ray, negative for a closest-hit ray; ray_d = direction
+// hit = closest: (t, node id bits, face | front << 31, u), hit_v = v;  any-hit: (1 or 0, 0, 0, 0)
+struct RayListIO {
+    const float4 *ray_o, *ray_d;
+    float4 *hit;
+    float *hit_v;
+    RT_DEV bool fetch(uint32_t e, float4 &o, float4 &d, bool &any_hit, float &t_max) const
+    {
+        o = ray_o[e]; d = ray_d[e];
+        any_hit = !(o.w < 0.0f); t_max = o.w;
+        return true;
+    }
+    RT_DEV void put_closest(uint32_t e, float t, int node, uint32_t face, int front, float u, float v) const
+    {
+        hit[e] = make_float4(t, __uint_as_float((uint32_t)node), __uint_as_float(face | ((uint32_t)front << 31)), u);
+        hit_v[e] = v;
+    }
+    RT_DEV void put_shadow(uint32_t e, bool occluded) const { hit[e] = make_float4(occluded ? 1.0f : 0.0f, 0.0f, 0.0f, 0.0f); }
+};
+
+#ifndef RT_RAYS_MIN_WAVES
+#define RT_RAYS_MIN_WAVES 4 // 120 registers, nothing spilled: faster than 6 waves with the walk's temporaries in scratch
+#endif
+#ifndef RT_RAYS_BVH_MIN_LANES
+#define RT_RAYS_BVH_MIN_LANES 32 // keep taking BVH steps while at least this many lanes are inside a mesh
+#endif
+#ifndef RT_RAYS_LEAF_MIN_LANES
+#define RT_RAYS_LEAF_MIN_LANES 16 // run triangle tests once this many lanes are parked at a leaf
+#endif
+#ifndef RT_RAYS_REFILL_MIN_LANES
+#define RT_RAYS_REFILL_MIN_LANES 24 // fetch new rays once this many lanes are idle
+#endif
+
+constexpr uint32_t kRayChunk = 256; // rays a wave reserves per queue atomic
+
+template <bool COUNT, int LEVELS, class IO>
+__global__ __launch_bounds__(kBlock, RT_RAYS_MIN_WAVES) void k_rays(DScene S, IO io, uint32_t n_rays, DCounters *ctr,
+                                                                  unsigned long long *queue)
+{
+    extern __shared__ uint32_t lds[];
+    const LaneStack st = lane_stack(lds, S);
+    const uint32_t lane = threadIdx.x & 63u;
+    const float epsilon = 1e-6f;
+    PathTally pt;
+    Tally<COUNT> tl;
+
+    // wave-uniform window of the ray list
+    uint32_t chunk_next = 0, chunk_end = 0;
+    bool exhausted = false;
+
+    // ---- per-lane state: one ray and its walk ----
+    bool active = false, any_hit = false, in_bvh = false;
+    uint32_t ray_i = 0;
+    Ray wray{mk(0, 0, 0), mk(0, 0, 1)}; // world space
+    float t_max = 0.0f;
+    int node_i = 0;                      // scene node being visited
+    RayLevels<LEVELS> lv;                // local rays of the hierarchy levels above it
+    lv.init(wray);
+    float best_t = FLT_MAX; int best_node = -1, best_front = 1; uint32_t best_face = 0; float best_u = 0, best_v = 0;
+    Ray lr = wray; V3 inv = mk(0, 0, 0); bool exact = false;
+    GF4 bvh = nullptr, tris = nullptr;
+    int sp = 0; float t_limit = 0.0f;
+    bool m_hit = false; uint32_t m_face = 0; float m_u = 0, m_v = 0, m_det = 0;
+    bool at_leaf = false; uint32_t leaf_data = 0, leaf_i = 0;
+
+    auto shadow_done = [&](bool occluded) {
+        io.put_shadow(ray_i, occluded);
+        active = false;
+    };
+
+    for (;;) {
+        // ================= refill idle lanes from the list =================
+        const uint64_t idle = __ballot(!active);
+        if (idle != 0 && !exhausted && ((uint32_t)__popcll(idle) >= (uint32_t)RT_RAYS_REFILL_MIN_LANES || idle == ~0ull || !__any(in_bvh))) {
+            if (chunk_next >= chunk_end) {
+                unsigned long long b = 0;
+                if (lane == 0) b = atomicAdd(queue, (unsigned long long)kRayChunk);
+                b = __shfl(b, 0, 64);
+                chunk_next = b < n_rays ? (uint32_t)b : n_rays;
+                chunk_end = b + kRayChunk < n_rays ? (uint32_t)(b + kRayChunk) : n_rays;
+                if (chunk_next >= chunk_end) exhausted = true;
+            }
+            const uint32_t avail = chunk_end - chunk_next;
+            const uint32_t want = (uint32_t)__popcll(idle);
+            const uint32_t take = avail < want ? avail : want;
+            const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            if (!active && rank < take) {
+                ray_i = chunk_next + rank;
+                float4 o, d;
+                if (io.fetch(ray_i, o, d, any_hit, t_max)) { // a list may have holes
+                    wray.p = mk(o.x, o.y, o.z); wray.d = mk(d.x, d.y, d.z);
+                    if (any_hit) ++pt.shadow; else ++pt.closest;
+                    node_i = 0; in_bvh = false; active = true;
+                    best_t = FLT_MAX; best_node = -1; best_front = 1; best_face = 0; best_u = 0; best_v = 0;
+                }
+            }
+            chunk_next += take;
+        }
+        if (!__any(active)) {
+            if (exhausted) break; // every wave gets here: the queue word only grows
+            continue;
+        }
+
+        // ================= scene-graph steps of rays that are not inside a mesh (main.cpp:16-89) =================
+        while (__any(active && !in_bvh)) {
+            if (active && !in_bvh) {
+                if (node_i < S.n_nodes) {
+                    const DNode &nd = S.nodes[node_i];
+                    const int d = nd.depth;
+                    const Ray parent = (d == 0) ? wray : lv.get(d - 1);
+                    lr = to_node(nd, parent);
+                    if (nd.has_children) lv.set(d, lr);
+                    const int prim = nd.prim;
+                    bool advance = true;
+                    if (prim == RT_PRIM_SPHERE || prim == RT_PRIM_PLANE) {
+                        if (any_hit) {
+                            const bool occ = prim == RT_PRIM_SPHERE ? sphere_shadow(lr, t_max) : plane_shadow(lr, t_max);
+                            if (occ) { shadow_done(true); advance = false; }
+                        } else {
+                            float t = 0; int front = 1;
+                            const bool ok = prim == RT_PRIM_SPHERE ? sphere_t(lr, t, front) : plane_t(lr, t, front);
+                            if (ok && t < best_t) { best_t = t; best_node = node_i; best_front = front; best_face = 0; best_u = 0; best_v = 0; }
+                        }
+                    } else if (prim == RT_PRIM_MESH) {
+                        const DMesh &M = S.meshes[nd.mesh];
+                        bvh = (GF4)M.bvh; tris = (GF4)M.tris;
+                        inv = mk(1.0f / lr.d.x, 1.0f / lr.d.y, 1.0f / lr.d.z);
+                        exact = needs_exact_slabs(lr.p, inv);
+                        t_limit = any_hit ? t_max : FLT_MAX;
+                        m_hit = false;
+                        const f4 r0 = bvh[2], r1 = bvh[3];
+                        float dist;
+                        tl.boxes(1);
+                        if (bvh_box(exact, lr.p, inv, t_limit, r0, r1, dist)) {
+                            st.push(0, __float_as_uint(r1.z), dist);
+                            sp = 1; in_bvh = true; advance = false;
+                        }
+                    }
+                    if (advance) ++node_i;
+                } else if (any_hit) {
+                    shadow_done(false); // nothing in the way
+                } else {
+                    // closest ray: the spherical lights last (main.cpp:52-70, lights.h:129-156), front side only
+                    for (int l = 0; l < S.n_lights; ++l) {
+                        const rt_light &L = S.lights[l];
+                        if (L.type != RT_LIGHT_POINT) continue;
+                        Ray r;
+                        r.p = (wray.p - ld3(L.position)) / L.size;
+                        r.d = wray.d / L.size;
+                        const float a = dot(r.d, r.d);
+                        const float b = 2 * dot(r.d, r.p);
+                        const float c = dot(r.p, r.p) - 1.0f;
+                        const float disc = b * b - 4 * a * c;
+                        if (disc < 0.0f) continue;
+                        const float s = fsqrt(disc);
+                        const float inv2a = 1.0f / (2.0f * a);
+                        const float t1 = (-b - s) * inv2a;
+                        if (t1 <= 0.0f) continue;
+                        if (t1 < best_t) { best_t = t1; best_node = -2 - l; best_front = 1; break; }
+                    }
+                    io.put_closest(ray_i, best_t, best_node, best_face, best_front, best_u, best_v);
+                    active = false;
+                }
+            }
+        }
+
+        // ================= BVH steps (TriObj.cpp:30-122 / 149-226) =================
+        // A walking lane pops one stack entry per trip and tests the two children of an inner node.
+        // A lane that pops a leaf parks there: triangle tests are long and only a few lanes reach a
+        // leaf in any one trip, so they run for many lanes at once.
+        while (__any(in_bvh)) {
+            if (in_bvh && !at_leaf) {
+                --sp;
+                uint32_t data; float nodeT;
+                st.pop(sp, data, nodeT);
+                if (!(t_limit < nodeT)) { // else: entered farther than the best hit so far
+                    if (data & kLeafBit) { at_leaf = true; leaf_data = data; leaf_i = 0; }
+                    else {
+                        const uint32_t c1 = data & 0x7FFFFFFFu;
+                        const f4 a0 = bvh[c1 * 2], a1 = bvh[c1 * 2 + 1], b0 = bvh[c1 * 2 + 2], b1 = bvh[c1 * 2 + 3];
+                        float d1, d2;
+                        tl.boxes(2);
+                        bool h1 = bvh_box(exact, lr.p, inv, t_limit, a0, a1, d1);
+                        h1 = h1 && d1 < t_limit;
+                        bool h2 = bvh_box(exact, lr.p, inv, t_limit, b0, b1, d2);
+                        h2 = h2 && d2 < t_limit;
+                        const uint32_t k1 = __float_as_uint(a1.z), k2 = __float_as_uint(b1.z);
+                        if (h1 && h2) {
+                            const bool firstNear = d1 < d2; // nearer child on top; on a tie the second child is visited first
+                            st.push(sp, firstNear ? k2 : k1, firstNear ? d2 : d1); ++sp;
+                            st.push(sp, firstNear ? k1 : k2, firstNear ? d1 : d2); ++sp;
+                        } else if (h1 || h2) {
+                            st.push(sp, h1 ? k1 : k2, h1 ? d1 : d2); ++sp;
+                        }
+                    }
+                }
+            }
+            const uint32_t n_leaf = (uint32_t)__popcll(__ballot(at_leaf));
+            const uint32_t n_walk = (uint32_t)__popcll(__ballot(in_bvh && !at_leaf));
+            if (n_leaf != 0 && (n_leaf >= (uint32_t)RT_RAYS_LEAF_MIN_LANES || n_leaf >= n_walk)) {
+                if (at_leaf) { // two triangles of the leaf per visit: six loads in flight together
+                    const uint32_t off = leaf_data & 0x0FFFFFFFu;
+                    const uint32_t cnt = ((leaf_data >> 28) & 7u) + 1;
+                    const GF4 ra = &tris[(off + leaf_i) * 3];
+                    const bool two = leaf_i + 1 < cnt;
+                    const GF4 rb = two ? ra + 3 : ra;
+                    const f4 a0 = ra[0], a1 = ra[1], a2 = ra[2], b0 = rb[0], b1 = rb[1], b2 = rb[2];
+                    float t, u, v, det; uint32_t face;
+                    bool stop = false;
+                    tl.tris(1);
+                    if (tri_test(a0, a1, a2, lr, t, u, v, det, face) && !(t <= epsilon || t > t_limit)) {
+                        m_hit = true; m_det = det; m_u = u; m_v = v; m_face = face; t_limit = t;
+                        stop = any_hit; // first hit ends a shadow ray
+                    }
+                    if (two && !stop) {
+                        tl.tris(1);
+                        if (tri_test(b0, b1, b2, lr, t, u, v, det, face) && !(t <= epsilon || t > t_limit)) {
+                            m_hit = true; m_det = det; m_u = u; m_v = v; m_face = face; t_limit = t;
+                            stop = any_hit;
+                        }
+                    }
+                    leaf_i += 2;
+                    if (stop) { sp = 0; at_leaf = false; }
+                    else if (leaf_i >= cnt) at_leaf = false;
+                }
+            }
+            if (in_bvh && !at_leaf && sp == 0) { // mesh done: fold its result into the ray's (main.cpp:38-48 / 80-85)
+                in_bvh = false;
+                if (any_hit) {
+                    if (m_hit) shadow_done(true);
+                    else ++node_i;
+                } else {
+                    if (m_hit && t_limit < best_t) {
+                        best_t = t_limit; best_node = node_i; best_front = m_det > 0.0f; best_face = m_face; best_u = m_u; best_v = m_v;
+                    }
+                    ++node_i;
+                }
+            }
+            if ((uint32_t)__popcll(__ballot(in_bvh)) < (uint32_t)RT_RAYS_BVH_MIN_LANES) break;
+        }
+    }
+    flush_counters<COUNT>(ctr, pt, tl, 0);
+}
+
+} // namespace rtd

@@ -25,7 +25,7 @@ struct DNode {
 }; // 160 bytes
 
 // One triangle mesh.
-//   bvh  : 32-byte nodes, two float4 each: (min.xyz, max.x) (max.y, max.z, data, 0);
+//   bvh  : 32-byte nodes, two float4 each: (min.x, max.x, min.y, max.y) (min.z, max.z, data, 0);
 //          the two children of a node are adjacent, the pair starts on a 64-byte line
 //   tris : 48-byte records in BVH-leaf order (indexed by element slot, not face id):
 //          (v0.xyz, v1.x) (v1.yz, v2.xy) (v2.z, face id, 0, 0) - the three position

@@ -35,20 +35,26 @@ struct Hit {
 // exactly once, whatever level each lane is at); deeper entries, which are rare, go
 // to a global overflow array laid out the same way.
 constexpr uint32_t kStackStride = 256;
+// The two homes of the stack are named by address space, so the compiler emits ds_read/ds_write
+// and global_load/global_store; through generic pointers it would emit flat instructions, which
+// take the slower path and wait on two counters.
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) u32x2 *LdsStackPtr;
+typedef __attribute__((address_space(1))) u32x2 *GlobalStackPtr;
 struct LaneStack {
-    uint2 *lds;          // &entries[threadIdx.x]
-    uint2 *ovf;          // &overflow[global thread id]
+    LdsStackPtr lds;     // &entries[threadIdx.x]
+    GlobalStackPtr ovf;  // &overflow[global thread id]
     uint32_t lds_levels;
     uint32_t ovf_stride; // threads in the grid
     RT_DEV void push(int sp, uint32_t data, float dist) const
     {
-        const uint2 e = make_uint2(data, __float_as_uint(dist));
+        const u32x2 e = {data, __float_as_uint(dist)};
         if ((uint32_t)sp < lds_levels) lds[(uint32_t)sp * kStackStride] = e;
         else ovf[(size_t)((uint32_t)sp - lds_levels) * ovf_stride] = e;
     }
     RT_DEV void pop(int sp, uint32_t &data, float &dist) const
     {
-        uint2 e;
+        u32x2 e;
         if ((uint32_t)sp < lds_levels) e = lds[(uint32_t)sp * kStackStride];
         else e = ovf[(size_t)((uint32_t)sp - lds_levels) * ovf_stride];
         data = e.x; dist = __uint_as_float(e.y);
@@ -134,47 +140,62 @@ typedef const RT_GLOBAL_AS uint32_t *GU32;
 RT_DEV V3 gld3(GF32 p) { return mk(p[0], p[1], p[2]); }
 
 // ---- BVH slab test (src/TriObj.cpp:272-320); inv = 1/dir computed once per ray ----
+// A node is two 16-byte pieces: b0 = (min.x, max.x, min.y, max.y), b1 = (min.z, max.z, data, 0).
 // Written without the early returns of the reference: the three slabs are always
-// evaluated and the three "tNear > tFar" rejects are combined at the end.  The
-// result is the same predicate and the same entry distance (it is a pure function
-// of its inputs), but the node's bounds are fetched with one group of wide loads
-// instead of three dependent partial ones.
+// evaluated and the rejects are combined at the end.  The result is the same predicate
+// and the same entry distance (it is a pure function of its inputs).
 //
-// EXACT selects with std::min/std::max operand order, so a NaN (0 * inf: a ray
+// The exact form keeps std::min/std::max operand order, so a NaN (0 * inf: a ray
 // direction component of exactly 0 with the origin exactly on a slab plane) goes
-// where it goes in the reference.  The fast form uses the min/max instructions; it
-// is used only for rays whose 1/dir is finite in all three components, for which no
-// NaN can arise and both forms agree in every bit that is compared.
-template <bool EXACT> RT_DEV float bmin(float a, float b) { return EXACT ? std_min(a, b) : fminf(a, b); }
-template <bool EXACT> RT_DEV float bmax(float a, float b) { return EXACT ? std_max(a, b) : fmaxf(a, b); }
+// where it goes in the reference.  The fast form is used only for rays whose origin and
+// 1/dir are finite in all three components: then no NaN can arise, min and max are exact
+// and associative, the running tNear only grows and tFar only shrinks, so the reference's
+// three "tNear > tFar" rejects and its final "tNear < tFar" collapse into the last one.
+// The min/max instructions are issued directly: through fminf/fmaxf the compiler adds a
+// canonicalising instruction per operand, a third of the test's instruction count.
+RT_DEV float vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+RT_DEV float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+RT_DEV float vmin3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+RT_DEV float vmax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+typedef float f2 __attribute__((ext_vector_type(2)));
 
-template <bool EXACT>
-RT_DEV bool bvh_box_t(V3 p, V3 inv, float t_max, f4 b0, f4 b1, float &dist)
+RT_DEV bool bvh_box_fast(V3 p, V3 inv, float t_max, f4 b0, f4 b1, float &dist)
+{
+    // (t at the min plane, t at the max plane) per axis: packed subtract and multiply
+    const f2 tx = (f2{b0.x, b0.y} - f2{p.x, p.x}) * f2{inv.x, inv.x};
+    const f2 ty = (f2{b0.z, b0.w} - f2{p.y, p.y}) * f2{inv.y, inv.y};
+    const f2 tz = (f2{b1.x, b1.y} - f2{p.z, p.z}) * f2{inv.z, inv.z};
+    const float tNear = vmax(vmax3(vmin(tx.x, tx.y), vmin(ty.x, ty.y), vmin(tz.x, tz.y)), 0.0f);
+    const float tFar = vmin(vmin3(vmax(tx.x, tx.y), vmax(ty.x, ty.y), vmax(tz.x, tz.y)), t_max);
+    dist = tNear;
+    return tNear < tFar;
+}
+RT_DEV bool bvh_box_exact(V3 p, V3 inv, float t_max, f4 b0, f4 b1, float &dist)
 {
     float tNear = 0.0f;
     float tFar = t_max;
     float t1 = (b0.x - p.x) * inv.x;
-    float t2 = (b0.w - p.x) * inv.x;
-    tNear = bmax<EXACT>(tNear, bmin<EXACT>(t1, t2));
-    tFar = bmin<EXACT>(tFar, bmax<EXACT>(t2, t1));
+    float t2 = (b0.y - p.x) * inv.x;
+    tNear = std_max(tNear, std_min(t1, t2));
+    tFar = std_min(tFar, std_max(t2, t1));
     bool ok = !(tNear > tFar);
-    t1 = (b0.y - p.y) * inv.y;
-    t2 = (b1.x - p.y) * inv.y;
-    tNear = bmax<EXACT>(tNear, bmin<EXACT>(t1, t2));
-    tFar = bmin<EXACT>(tFar, bmax<EXACT>(t1, t2));
+    t1 = (b0.z - p.y) * inv.y;
+    t2 = (b0.w - p.y) * inv.y;
+    tNear = std_max(tNear, std_min(t1, t2));
+    tFar = std_min(tFar, std_max(t1, t2));
     ok = ok && !(tNear > tFar);
-    t1 = (b0.z - p.z) * inv.z;
+    t1 = (b1.x - p.z) * inv.z;
     t2 = (b1.y - p.z) * inv.z;
-    tNear = bmax<EXACT>(tNear, bmin<EXACT>(t1, t2));
-    tFar = bmin<EXACT>(tFar, bmax<EXACT>(t1, t2));
+    tNear = std_max(tNear, std_min(t1, t2));
+    tFar = std_min(tFar, std_max(t1, t2));
     ok = ok && !(tNear > tFar) && (tNear < tFar);
     dist = tNear;
     return ok;
 }
 RT_DEV bool bvh_box(bool exact, V3 p, V3 inv, float t_max, f4 b0, f4 b1, float &dist)
 {
-    if (__builtin_expect(exact, 0)) return bvh_box_t<true>(p, inv, t_max, b0, b1, dist);
-    return bvh_box_t<false>(p, inv, t_max, b0, b1, dist);
+    if (__builtin_expect(exact, 0)) return bvh_box_exact(p, inv, t_max, b0, b1, dist);
+    return bvh_box_fast(p, inv, t_max, b0, b1, dist);
 }
 // entry distance alone (same operations, same bits)
 RT_DEV float bvh_near(bool exact, V3 p, V3 inv, f4 b0, f4 b1)
@@ -183,9 +204,10 @@ RT_DEV float bvh_near(bool exact, V3 p, V3 inv, f4 b0, f4 b1)
     (void)bvh_box(exact, p, inv, FLT_MAX, b0, b1, d);
     return d;
 }
-RT_DEV bool needs_exact_slabs(V3 inv)
+RT_DEV bool needs_exact_slabs(V3 p, V3 inv)
 {
-    return !(fabsf(inv.x) < INFINITY && fabsf(inv.y) < INFINITY && fabsf(inv.z) < INFINITY);
+    return !(fabsf(inv.x) < INFINITY && fabsf(inv.y) < INFINITY && fabsf(inv.z) < INFINITY &&
+             fabsf(p.x) < INFINITY && fabsf(p.y) < INFINITY && fabsf(p.z) < INFINITY);
 }
 
 // one Moeller-Trumbore test (src/TriObj.cpp:46-74) up to, not including, the range test on t
@@ -223,7 +245,7 @@ RT_DEV bool mesh_traverse(const DMesh &M, Ray r, float t_limit, bool any_hit, La
 {
     const float epsilon = 1e-6f;
     const V3 inv = mk(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
-    const bool exact = needs_exact_slabs(inv);
+    const bool exact = needs_exact_slabs(r.p, inv);
     const GF4 bvh = (GF4)M.bvh, tris = (GF4)M.tris;
     int sp = 0;
     {

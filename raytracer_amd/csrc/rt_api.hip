@@ -2,6 +2,7 @@
 // Host-side control only; the arithmetic lives in device/*.h.
 #include "device/wavefront.h"
 #include "device/pathsm.h"
+#include "device/rays.h"
 #include "rt_mi355x.h"
 
 #include <algorithm>
@@ -60,7 +61,7 @@ struct rt_ctx {
     DeviceBuf d_halton, d_active[2], d_next_count, d_state, d_sbuf, d_counters, d_queue;
     DeviceBuf d_stack_ovf;
     // wavefront pipeline: path pool, ray queue, counters {count, alive, pad, pad, head(u64), item(u64)}
-    DeviceBuf d_pool, d_wq_rays, d_wq_ctr;
+    DeviceBuf d_pool, d_wq_ctr;
     uint32_t pool_slots = 0;
     uint32_t pool_max = 1u << 22;
     bool use_wavefront = false; // RT_PIPELINE=wave: separate logic / ray-queue kernels
@@ -166,67 +167,79 @@ const void *paths_kernel(bool counting, int ray_levels, bool lockstep)
     return counting ? (const void *)k_paths<true, 5> : (const void *)k_paths<false, 5>;
 }
 
+const void *rays_kernel(bool counting, int ray_levels)
+{
+    if (ray_levels <= 1) return counting ? (const void *)k_rays<true, 1, RayListIO> : (const void *)k_rays<false, 1, RayListIO>;
+    if (ray_levels == 2) return counting ? (const void *)k_rays<true, 2, RayListIO> : (const void *)k_rays<false, 2, RayListIO>;
+    return counting ? (const void *)k_rays<true, 5, RayListIO> : (const void *)k_rays<false, 5, RayListIO>;
+}
+
 const void *wf_trace_kernel(bool counting, int ray_levels)
 {
-    if (ray_levels <= 1) return counting ? (const void *)k_wf_trace<true, 1> : (const void *)k_wf_trace<false, 1>;
-    if (ray_levels == 2) return counting ? (const void *)k_wf_trace<true, 2> : (const void *)k_wf_trace<false, 2>;
-    return counting ? (const void *)k_wf_trace<true, 5> : (const void *)k_wf_trace<false, 5>;
+    if (ray_levels <= 1) return counting ? (const void *)k_rays<true, 1, PoolIO> : (const void *)k_rays<false, 1, PoolIO>;
+    if (ray_levels == 2) return counting ? (const void *)k_rays<true, 2, PoolIO> : (const void *)k_rays<false, 2, PoolIO>;
+    return counting ? (const void *)k_rays<true, 5, PoolIO> : (const void *)k_rays<false, 5, PoolIO>;
 }
 
 size_t stack_lds_bytes(const DScene &S) { return (size_t)S.lds_levels * kBlock * 8; }
 
 } // namespace
 
-// One launch range through the wavefront pipeline: alternate k_wf_logic (shade, emit
-// rays, refill slots) and k_wf_trace (drain the ray queue) until no slot holds a path.
+// One launch range through the wavefront pipeline: alternate k_wf_logic (shade, leave rays in
+// the slots, refill) and k_rays over the pool until no slot holds a path.  The host looks at the
+// alive count only every few rounds; a round on a pool that has emptied meanwhile does nothing.
 static int render_wavefront(rt_ctx *ctx, const DFrame &F, const int32_t *act, uint64_t items, int k0, int nk,
                             const FramePlanes &planes, size_t lds)
 {
     hipStream_t s = ctx->stream;
     const uint32_t slots = (uint32_t)std::min<uint64_t>(ctx->pool_max, (items + kBlock - 1) / kBlock * kBlock);
     // pool arrays, 256-byte aligned sub-allocations of one buffer
-    const size_t sizes[12] = {16, 16, 16, 16, 8, 16, 16, 8, 16, 16, 16, 4};
-    size_t offs[12], total = 0;
-    for (int i = 0; i < 12; ++i) { offs[i] = total; total += ((size_t)slots * sizes[i] + 255) / 256 * 256; }
+    const size_t sizes[13] = {16, 16, 16, 16, 8, 16, 16, 8, 16, 16, 16, 4, 4};
+    size_t offs[13], total = 0;
+    for (int i = 0; i < 13; ++i) { offs[i] = total; total += ((size_t)slots * sizes[i] + 255) / 256 * 256; }
     HIP_TRY(ctx, ctx->d_pool.reserve(total));
-    HIP_TRY(ctx, ctx->d_wq_rays.reserve((size_t)slots * 2 * sizeof(uint32_t)));
-    HIP_TRY(ctx, ctx->d_wq_ctr.reserve(64));
+    const dim3 logic_grid((unsigned)std::min<uint64_t>(slots / kBlock, (uint64_t)ctx->n_cu * 6));
+    HIP_TRY(ctx, ctx->d_wq_ctr.reserve(64 + (size_t)logic_grid.x * 16));
     char *base = ctx->d_pool.as<char>();
     WfPool P{};
     P.ray_o = (float4 *)(base + offs[0]); P.ray_d = (float4 *)(base + offs[1]); P.thr = (float4 *)(base + offs[2]);
     P.res = (float4 *)(base + offs[3]); P.rng = (uint2 *)(base + offs[4]); P.meta = (uint4 *)(base + offs[5]);
     P.hit = (float4 *)(base + offs[6]); P.hit_uv = (float2 *)(base + offs[7]); P.sh_o = (float4 *)(base + offs[8]);
     P.sh_d = (float4 *)(base + offs[9]); P.contrib = (float4 *)(base + offs[10]); P.vis = (uint32_t *)(base + offs[11]);
+    P.flags = (uint32_t *)(base + offs[12]);
     P.n_slots = slots;
     char *cb = ctx->d_wq_ctr.as<char>();
     WfQueue Q{};
-    Q.rays = ctx->d_wq_rays.as<uint32_t>();
-    Q.count = (uint32_t *)cb; Q.alive = (uint32_t *)(cb + 4);
-    Q.head = (unsigned long long *)(cb + 16); Q.item = (unsigned long long *)(cb + 24);
+    Q.alive = (uint32_t *)cb; Q.item = (unsigned long long *)(cb + 8); Q.block_items = (unsigned long long *)(cb + 64);
 
     const void *fn = wf_trace_kernel(ctx->counting, ctx->ray_levels);
     int per_cu = 1;
     HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kBlock, lds));
     per_cu = std::max(1, std::min(per_cu, 8));
-    const dim3 trace_grid((unsigned)(ctx->n_cu * per_cu));
-    const dim3 logic_grid(slots / kBlock);
+    const dim3 trace_grid((unsigned)std::min<uint64_t>((uint64_t)ctx->n_cu * per_cu, (2ull * slots + kBlock - 1) / kBlock));
 
-    HIP_TRY(ctx, hipMemsetAsync(cb, 0, 32, s));
+    HIP_TRY(ctx, hipMemsetAsync(cb, 0, 16, s));
     DScene a_scene = ctx->scene;
+    PoolIO a_io{P};
+    uint32_t a_n = 2 * slots;
     DCounters *a_ctr = ctx->d_counters.as<DCounters>();
-    void *targs[] = {&a_scene, &P, &Q, &a_ctr};
+    unsigned long long *a_queue = ctx->d_queue.as<unsigned long long>();
+    void *targs[] = {&a_scene, &a_io, &a_n, &a_ctr, &a_queue};
+    const uint32_t check_every = 8;
     int first = 1;
     for (uint32_t iter = 0;; ++iter) {
-        HIP_TRY(ctx, hipMemsetAsync(cb, 0, 24, s)); // count, alive, head; the item counter runs on
+        HIP_TRY(ctx, hipMemsetAsync(cb, 0, 4, s)); // alive; the item counter runs on
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue.p, 0, kQueueBytes, s));
         hipLaunchKernelGGL(k_wf_logic, logic_grid, dim3(kBlock), 0, s, ctx->scene, F, ctx->d_halton.as<float>(), act, items, k0, nk,
                            ctx->d_sbuf.as<float4>(), planes, P, Q, a_ctr, first);
         HIP_TRY(ctx, hipGetLastError());
         first = 0;
         HIP_TRY(ctx, hipLaunchKernel(fn, trace_grid, dim3(kBlock), targs, lds, s));
-        uint32_t h[2] = {0, 0};
-        HIP_TRY(ctx, hipMemcpyAsync(h, cb, sizeof h, hipMemcpyDeviceToHost, s));
+        if (iter % check_every != check_every - 1) continue;
+        uint32_t alive = 0;
+        HIP_TRY(ctx, hipMemcpyAsync(&alive, cb, sizeof alive, hipMemcpyDeviceToHost, s));
         HIP_TRY(ctx, hipStreamSynchronize(s));
-        if (h[1] == 0) break; // no slot holds a path any more
+        if (alive == 0) break; // no slot holds a path any more
         if (iter > (1u << 24)) return ctx->fail(RT_ERR_HIP, "wavefront loop did not terminate");
     }
     return RT_OK;
@@ -262,12 +275,14 @@ int rt_init(int device, rt_ctx **out)
     if ((e = ctx->d_counters.reserve(sizeof(DCounters))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = ctx->d_next_count.reserve(sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
     // per-lane BVH stacks may need more than the default 64 KiB of LDS per workgroup
-    for (const void *k : {(const void *)k_path_sm<false, 1>, (const void *)k_path_sm<false, 2>, (const void *)k_path_sm<false, 5>,
+    for (const void *k : {(const void *)k_rays<false, 1, RayListIO>, (const void *)k_rays<false, 2, RayListIO>, (const void *)k_rays<false, 5, RayListIO>,
+                          (const void *)k_rays<true, 1, RayListIO>, (const void *)k_rays<true, 2, RayListIO>, (const void *)k_rays<true, 5, RayListIO>,
+                          (const void *)k_path_sm<false, 1>, (const void *)k_path_sm<false, 2>, (const void *)k_path_sm<false, 5>,
                           (const void *)k_path_sm<true, 1>, (const void *)k_path_sm<true, 2>, (const void *)k_path_sm<true, 5>,
                           (const void *)k_paths<false, 1>, (const void *)k_paths<false, 2>, (const void *)k_paths<false, 5>,
                           (const void *)k_paths<true, 1>, (const void *)k_paths<true, 2>, (const void *)k_paths<true, 5>,
-                          (const void *)k_wf_trace<false, 1>, (const void *)k_wf_trace<false, 2>, (const void *)k_wf_trace<false, 5>,
-                          (const void *)k_wf_trace<true, 1>, (const void *)k_wf_trace<true, 2>, (const void *)k_wf_trace<true, 5>,
+                          (const void *)k_rays<false, 1, PoolIO>, (const void *)k_rays<false, 2, PoolIO>, (const void *)k_rays<false, 5, PoolIO>,
+                          (const void *)k_rays<true, 1, PoolIO>, (const void *)k_rays<true, 2, PoolIO>, (const void *)k_rays<true, 5, PoolIO>,
                           (const void *)k_trace, (const void *)k_trace_shadow, (const void *)k_trace_paths})
         (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipDeviceProp_t prop;
@@ -378,8 +393,9 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc)
             if (id == 0 || id >= m.n_bvh_nodes || ++visited > m.n_bvh_nodes) return ctx->fail(RT_ERR_INVALID, "mesh %u: BVH node index out of range or cyclic", mi);
             depth = std::max(depth, lvl);
             const rt_bvh_node &b = m.bvh_nodes[id];
-            bvh[id * 2] = make_float4(b.bounds[0], b.bounds[1], b.bounds[2], b.bounds[3]);
-            bvh[id * 2 + 1] = make_float4(b.bounds[4], b.bounds[5], __builtin_bit_cast(float, b.data), 0.0f);
+            // bounds = min.xyz, max.xyz; stored interleaved per axis (see bvh_box_fast)
+            bvh[id * 2] = make_float4(b.bounds[0], b.bounds[3], b.bounds[1], b.bounds[4]);
+            bvh[id * 2 + 1] = make_float4(b.bounds[2], b.bounds[5], __builtin_bit_cast(float, b.data), 0.0f);
             if (b.data & 0x80000000u) {
                 const uint32_t off = b.data & 0x0FFFFFFFu, cnt = ((b.data >> 28) & 7u) + 1;
                 if ((size_t)off + cnt > m.nf) return ctx->fail(RT_ERR_INVALID, "mesh %u: BVH leaf out of range", mi);
@@ -614,6 +630,16 @@ static dim3 batch_grid(const rt_ctx *ctx, int n)
     return dim3((unsigned)std::max<size_t>(1, std::min(want, ctx->ovf_threads / kBlock)));
 }
 
+// kernel duration of the batch query that just finished, for rt_get_counters
+static int batch_time(rt_ctx *ctx)
+{
+    float ms = 0;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->evk0, ctx->evk1));
+    ctx->counters = rt_counters{};
+    ctx->counters.kernel_ms = ms; ctx->counters.trace_kernel_ms = ms; ctx->counters.trace_launches = 1;
+    return RT_OK;
+}
+
 static int batch_common(rt_ctx *ctx, const float *rays6, int n)
 {
     if (!ctx) return RT_ERR_INVALID;
@@ -632,12 +658,14 @@ int rt_trace(rt_ctx *ctx, const float *rays6, int n, rt_hit *out)
     HIP_TRY(ctx, ctx->d_q_in.reserve((size_t)n * 24));
     HIP_TRY(ctx, ctx->d_q_out.reserve((size_t)n * sizeof(rt_hit)));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_q_in.p, rays6, (size_t)n * 24, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipEventRecord(ctx->evk0, s));
     hipLaunchKernelGGL(k_trace, batch_grid(ctx, n), dim3(kBlock), stack_lds_bytes(ctx->scene), s, ctx->scene,
                        ctx->d_q_in.as<float>(), n, ctx->d_q_out.as<rt_hit>());
     HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->evk1, s));
     HIP_TRY(ctx, hipMemcpyAsync(out, ctx->d_q_out.p, (size_t)n * sizeof(rt_hit), hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));
-    return RT_OK;
+    return batch_time(ctx);
 }
 
 int rt_trace_shadow(rt_ctx *ctx, const float *rays6, const float *t_max, int n, int32_t *occluded)
@@ -652,11 +680,74 @@ int rt_trace_shadow(rt_ctx *ctx, const float *rays6, const float *t_max, int n, 
     HIP_TRY(ctx, ctx->d_q_out.reserve((size_t)n * 4));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_q_in.p, rays6, (size_t)n * 24, hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_q_aux.p, t_max, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipEventRecord(ctx->evk0, s));
     hipLaunchKernelGGL(k_trace_shadow, batch_grid(ctx, n), dim3(kBlock), stack_lds_bytes(ctx->scene), s, ctx->scene,
                        ctx->d_q_in.as<float>(), ctx->d_q_aux.as<float>(), n, ctx->d_q_out.as<int32_t>());
     HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->evk1, s));
     HIP_TRY(ctx, hipMemcpyAsync(occluded, ctx->d_q_out.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));
+    return batch_time(ctx);
+}
+
+int rt_trace_brief(rt_ctx *ctx, const float *rays6, const float *t_max, int n, rt_hit_brief *out)
+{
+    if (int rc = batch_common(ctx, rays6, n)) return rc;
+    if (n == 0) return RT_OK;
+    if (!out) return ctx->fail(RT_ERR_INVALID, "null output");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    std::vector<float4> od((size_t)n * 2);
+    for (int i = 0; i < n; ++i) {
+        const float *r = rays6 + (size_t)i * 6;
+        if (t_max && !(t_max[i] >= 0.0f)) return ctx->fail(RT_ERR_INVALID, "t_max[%d] must be >= 0", i);
+        od[i] = make_float4(r[0], r[1], r[2], t_max ? t_max[i] : -1.0f);
+        od[(size_t)n + i] = make_float4(r[3], r[4], r[5], 0.0f);
+    }
+    HIP_TRY(ctx, ctx->d_q_in.reserve((size_t)n * 32));
+    HIP_TRY(ctx, ctx->d_q_out.reserve((size_t)n * 16));
+    HIP_TRY(ctx, ctx->d_q_aux.reserve((size_t)n * 4));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_q_in.p, od.data(), (size_t)n * 32, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters.p, 0, sizeof(DCounters), s));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue.p, 0, kQueueBytes, s));
+    const void *fn = rays_kernel(ctx->counting, ctx->ray_levels);
+    const size_t lds = stack_lds_bytes(ctx->scene);
+    int per_cu = 1;
+    HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kBlock, lds));
+    per_cu = std::max(1, std::min(per_cu, 8));
+    const uint64_t want_blocks = ((uint64_t)n + kBlock - 1) / kBlock;
+    const dim3 grid((unsigned)std::min<uint64_t>(want_blocks, (uint64_t)ctx->n_cu * per_cu));
+    {
+        DScene a_scene = ctx->scene;
+        RayListIO a_io{ctx->d_q_in.as<float4>(), ctx->d_q_in.as<float4>() + n, ctx->d_q_out.as<float4>(), ctx->d_q_aux.as<float>()};
+        uint32_t a_n = (uint32_t)n;
+        DCounters *a_ctr = ctx->d_counters.as<DCounters>();
+        unsigned long long *a_queue = ctx->d_queue.as<unsigned long long>();
+        void *args[] = {&a_scene, &a_io, &a_n, &a_ctr, &a_queue};
+        HIP_TRY(ctx, hipEventRecord(ctx->evk0, s));
+        HIP_TRY(ctx, hipLaunchKernel(fn, grid, dim3(kBlock), args, lds, s));
+        HIP_TRY(ctx, hipEventRecord(ctx->evk1, s));
+    }
+    std::vector<float4> h((size_t)n);
+    std::vector<float> hv((size_t)n);
+    HIP_TRY(ctx, hipMemcpyAsync(h.data(), ctx->d_q_out.p, (size_t)n * 16, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipMemcpyAsync(hv.data(), ctx->d_q_aux.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    DCounters dc{};
+    HIP_TRY(ctx, hipMemcpyAsync(&dc, ctx->d_counters.p, sizeof dc, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    float ms = 0;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->evk0, ctx->evk1));
+    rt_counters &c = ctx->counters;
+    c = rt_counters{};
+    c.closest_rays = dc.closest; c.shadow_rays = dc.shadow; c.box_tests = dc.box_tests; c.tri_tests = dc.tri_tests;
+    c.kernel_ms = ms; c.trace_kernel_ms = ms; c.trace_launches = 1;
+    for (int i = 0; i < n; ++i) {
+        rt_hit_brief &o = out[i];
+        if (t_max) { o = rt_hit_brief{0.0f, h[i].x != 0.0f ? 1 : 0, 0u, 0, 0.0f, 0.0f}; continue; }
+        const uint32_t ff = __builtin_bit_cast(uint32_t, h[i].z);
+        o.t = h[i].x; o.node = (int32_t)__builtin_bit_cast(uint32_t, h[i].y);
+        o.face = ff & 0x7FFFFFFFu; o.front = (int32_t)(ff >> 31); o.u = h[i].w; o.v = hv[i];
+    }
     return RT_OK;
 }
 

@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("RT_LIB") or os.path.join(_HERE, "librt_mi355x.so")
 # every symbol include/rt_mi355x.h declares
 SYMBOLS = (
     "rt_abi_version", "rt_init", "rt_shutdown", "rt_last_error", "rt_scene_upload", "rt_camera_set", "rt_render",
-    "rt_trace", "rt_trace_shadow", "rt_trace_paths", "rt_get_counters", "rt_set_counting",
+    "rt_trace", "rt_trace_shadow", "rt_trace_brief", "rt_trace_paths", "rt_get_counters", "rt_set_counting",
     "rt_scene_load_xml", "rt_scene_from_xml_string", "rt_scene_host_desc", "rt_scene_host_camera",
     "rt_scene_host_free", "rt_scene_host_set_mesh", "rt_bvh_build", "rt_free",
 )
@@ -51,6 +51,7 @@ def load():
     L.rt_render.argtypes = [vp, C.POINTER(abi.RenderParams), C.POINTER(abi.FrameOut)]
     L.rt_trace.argtypes = [vp, abi.f32p, C.c_int, C.POINTER(abi.Hit)]
     L.rt_trace_shadow.argtypes = [vp, abi.f32p, abi.f32p, C.c_int, abi.i32p]
+    L.rt_trace_brief.argtypes = [vp, abi.f32p, abi.f32p, C.c_int, C.POINTER(abi.HitBrief)]
     L.rt_trace_paths.argtypes = [vp, abi.f32p, C.c_int, C.c_uint64, C.POINTER(abi.RenderParams), abi.f32p]
     L.rt_get_counters.argtypes = [vp, C.POINTER(abi.Counters)]
     L.rt_set_counting.argtypes = [vp, C.c_int]
@@ -207,6 +208,18 @@ class Context:
         out = np.zeros(len(rays), np.int32)
         self._check(self._L.rt_trace_shadow(self._h, rays.ctypes.data_as(abi.f32p), tmax.ctypes.data_as(abi.f32p),
                                             len(rays), out.ctypes.data_as(abi.i32p)))
+        return out
+
+    def trace_brief(self, rays, tmax=None):
+        """Closest hits (tmax None) or any-hit flags by the persistent ray-list kernel; see rt_trace_brief."""
+        rays = np.ascontiguousarray(rays, np.float32)
+        out = np.zeros(len(rays), abi.HIT_BRIEF_DTYPE)
+        tm = None
+        if tmax is not None:
+            tm = np.ascontiguousarray(tmax, np.float32)
+        self._check(self._L.rt_trace_brief(self._h, rays.ctypes.data_as(abi.f32p),
+                                           tm.ctypes.data_as(abi.f32p) if tm is not None else None, len(rays),
+                                           C.cast(out.ctypes.data, C.POINTER(abi.HitBrief))))
         return out
 
     def trace_paths(self, rays, seed, params):
