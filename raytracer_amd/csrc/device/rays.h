@@ -37,17 +37,22 @@ struct RayListIO {
 #ifndef RT_RAYS_MIN_WAVES
 #define RT_RAYS_MIN_WAVES 4 // 120 registers, nothing spilled: faster than 6 waves with the walk's temporaries in scratch
 #endif
+
 #ifndef RT_RAYS_BVH_MIN_LANES
 #define RT_RAYS_BVH_MIN_LANES 32 // keep taking BVH steps while at least this many lanes are inside a mesh
 #endif
 #ifndef RT_RAYS_LEAF_MIN_LANES
 #define RT_RAYS_LEAF_MIN_LANES 16 // run triangle tests once this many lanes are parked at a leaf
 #endif
+#ifndef RT_RAYS_SCENE_MIN_LANES
+#define RT_RAYS_SCENE_MIN_LANES 16 // run a pass over the scene nodes once this many lanes wait outside a mesh
+#endif
 #ifndef RT_RAYS_REFILL_MIN_LANES
 #define RT_RAYS_REFILL_MIN_LANES 24 // fetch new rays once this many lanes are idle
 #endif
 
 constexpr uint32_t kRayChunk = 256; // rays a wave reserves per queue atomic
+constexpr uint32_t kNoNode = 0x7FFFFFFFu; // not a data word: an inner node's first child index is far smaller
 
 template <bool COUNT, int LEVELS, class IO>
 __global__ __launch_bounds__(kBlock, RT_RAYS_MIN_WAVES) void k_rays(DScene S, IO io, uint32_t n_rays, DCounters *ctr,
@@ -78,16 +83,23 @@ __global__ __launch_bounds__(kBlock, RT_RAYS_MIN_WAVES) void k_rays(DScene S, IO
     int sp = 0; float t_limit = 0.0f;
     bool m_hit = false; uint32_t m_face = 0; float m_u = 0, m_v = 0, m_det = 0;
     bool at_leaf = false; uint32_t leaf_data = 0, leaf_i = 0;
+    uint32_t cur = kNoNode; // node to visit next (its data word), kNoNode: take one from the stack
 
     auto shadow_done = [&](bool occluded) {
         io.put_shadow(ray_i, occluded);
         active = false;
     };
 
+    // A lane is idle, stepping through the scene nodes, walking a BVH, or parked at a leaf.  The wave
+    // runs each kind of step for all lanes that wait for it at once, and lets lanes wait until enough
+    // of them do (thresholds above) or nothing else can run.  The schedule decides only when a lane
+    // takes its next step, never what the step computes.
+    pt.tick();
     for (;;) {
         // ================= refill idle lanes from the list =================
         const uint64_t idle = __ballot(!active);
-        if (idle != 0 && !exhausted && ((uint32_t)__popcll(idle) >= (uint32_t)RT_RAYS_REFILL_MIN_LANES || idle == ~0ull || !__any(in_bvh))) {
+        pt.tock(12);
+        if (idle != 0 && !exhausted && ((uint32_t)__popcll(idle) >= (uint32_t)RT_RAYS_REFILL_MIN_LANES || !__any(in_bvh))) {
             if (chunk_next >= chunk_end) {
                 unsigned long long b = 0;
                 if (lane == 0) b = atomicAdd(queue, (unsigned long long)kRayChunk);
@@ -111,6 +123,7 @@ __global__ __launch_bounds__(kBlock, RT_RAYS_MIN_WAVES) void k_rays(DScene S, IO
                 }
             }
             chunk_next += take;
+            pt.ran(0, idle);
         }
         if (!__any(active)) {
             if (exhausted) break; // every wave gets here: the queue word only grows
@@ -118,10 +131,16 @@ __global__ __launch_bounds__(kBlock, RT_RAYS_MIN_WAVES) void k_rays(DScene S, IO
         }
 
         // ================= scene-graph steps of rays that are not inside a mesh (main.cpp:16-89) =================
-        while (__any(active && !in_bvh)) {
-            if (active && !in_bvh) {
-                if (node_i < S.n_nodes) {
-                    const DNode &nd = S.nodes[node_i];
+        // One pass over the node list in step: the node index is wave-uniform, so node matrices arrive
+        // through scalar loads; a lane takes part from the node it has got to, and stays in the pass
+        // until it enters a mesh or runs off the end of the list.
+        const uint64_t stepping = __ballot(active && !in_bvh);
+        if (stepping != 0 && ((uint32_t)__popcll(stepping) >= (uint32_t)RT_RAYS_SCENE_MIN_LANES || !__any(in_bvh))) {
+            pt.tock(12);
+            for (int n = 0; n < S.n_nodes; ++n) {
+                if (!__any(active && !in_bvh && node_i == n)) continue;
+                const DNode &nd = S.nodes[n];
+                if (active && !in_bvh && node_i == n) {
                     const int d = nd.depth;
                     const Ray parent = (d == 0) ? wray : lv.get(d - 1);
                     lr = to_node(nd, parent);
@@ -135,7 +154,7 @@ __global__ __launch_bounds__(kBlock, RT_RAYS_MIN_WAVES) void k_rays(DScene S, IO
                         } else {
                             float t = 0; int front = 1;
                             const bool ok = prim == RT_PRIM_SPHERE ? sphere_t(lr, t, front) : plane_t(lr, t, front);
-                            if (ok && t < best_t) { best_t = t; best_node = node_i; best_front = front; best_face = 0; best_u = 0; best_v = 0; }
+                            if (ok && t < best_t) { best_t = t; best_node = n; best_front = front; best_face = 0; best_u = 0; best_v = 0; }
                         }
                     } else if (prim == RT_PRIM_MESH) {
                         const DMesh &M = S.meshes[nd.mesh];
@@ -148,14 +167,16 @@ __global__ __launch_bounds__(kBlock, RT_RAYS_MIN_WAVES) void k_rays(DScene S, IO
                         float dist;
                         tl.boxes(1);
                         if (bvh_box(exact, lr.p, inv, t_limit, r0, r1, dist)) {
-                            st.push(0, __float_as_uint(r1.z), dist);
-                            sp = 1; in_bvh = true; advance = false;
+                            cur = __float_as_uint(r1.z); // the root is the node to visit next; the stack is empty
+                            sp = 0; in_bvh = true; advance = false;
                         }
                     }
-                    if (advance) ++node_i;
-                } else if (any_hit) {
-                    shadow_done(false); // nothing in the way
-                } else {
+                    if (advance) node_i = n + 1;
+                }
+            }
+            if (active && !in_bvh && node_i >= S.n_nodes) {
+                if (any_hit) shadow_done(false); // nothing in the way
+                else {
                     // closest ray: the spherical lights last (main.cpp:52-70, lights.h:129-156), front side only
                     for (int l = 0; l < S.n_lights; ++l) {
                         const rt_light &L = S.lights[l];
@@ -178,21 +199,32 @@ __global__ __launch_bounds__(kBlock, RT_RAYS_MIN_WAVES) void k_rays(DScene S, IO
                     active = false;
                 }
             }
+            pt.ran(1, stepping);
         }
 
         // ================= BVH steps (TriObj.cpp:30-122 / 149-226) =================
-        // A walking lane pops one stack entry per trip and tests the two children of an inner node.
-        // A lane that pops a leaf parks there: triangle tests are long and only a few lanes reach a
-        // leaf in any one trip, so they run for many lanes at once.
+        // The node to visit next is kept in a register (cur): of two children that are hit only the
+        // farther one goes to the stack, the nearer one is visited in the next trip - exactly the
+        // order of the reference, which pushes both and pops the nearer one at once (its entry
+        // distance was just tested against the current closest hit, so the pop-time test of the
+        // reference cannot fail for it and is not repeated).  The stack is read only when a visit
+        // leaves nothing to go on with.
+        // A lane whose next node is a leaf parks there: triangle tests are long and only a few
+        // lanes reach a leaf in any one trip, so they run for many lanes at once.
         while (__any(in_bvh)) {
+            pt.tock(12);
+            const uint64_t walkers = __ballot(in_bvh && !at_leaf);
             if (in_bvh && !at_leaf) {
-                --sp;
-                uint32_t data; float nodeT;
-                st.pop(sp, data, nodeT);
-                if (!(t_limit < nodeT)) { // else: entered farther than the best hit so far
-                    if (data & kLeafBit) { at_leaf = true; leaf_data = data; leaf_i = 0; }
+                if (cur == kNoNode && sp > 0) {
+                    --sp;
+                    uint32_t data; float nodeT;
+                    st.pop(sp, data, nodeT);
+                    if (!(t_limit < nodeT)) cur = data; // else: entered farther than the best hit so far
+                }
+                if (cur != kNoNode) {
+                    if (cur & kLeafBit) { at_leaf = true; leaf_data = cur; leaf_i = 0; cur = kNoNode; }
                     else {
-                        const uint32_t c1 = data & 0x7FFFFFFFu;
+                        const uint32_t c1 = cur & 0x7FFFFFFFu;
                         const f4 a0 = bvh[c1 * 2], a1 = bvh[c1 * 2 + 1], b0 = bvh[c1 * 2 + 2], b1 = bvh[c1 * 2 + 3];
                         float d1, d2;
                         tl.boxes(2);
@@ -201,19 +233,17 @@ __global__ __launch_bounds__(kBlock, RT_RAYS_MIN_WAVES) void k_rays(DScene S, IO
                         bool h2 = bvh_box(exact, lr.p, inv, t_limit, b0, b1, d2);
                         h2 = h2 && d2 < t_limit;
                         const uint32_t k1 = __float_as_uint(a1.z), k2 = __float_as_uint(b1.z);
-                        if (h1 && h2) {
-                            const bool firstNear = d1 < d2; // nearer child on top; on a tie the second child is visited first
-                            st.push(sp, firstNear ? k2 : k1, firstNear ? d2 : d1); ++sp;
-                            st.push(sp, firstNear ? k1 : k2, firstNear ? d1 : d2); ++sp;
-                        } else if (h1 || h2) {
-                            st.push(sp, h1 ? k1 : k2, h1 ? d1 : d2); ++sp;
-                        }
+                        const bool firstNear = d1 < d2; // on a tie the second child is visited first
+                        if (h1 && h2) { st.push(sp, firstNear ? k2 : k1, firstNear ? d2 : d1); ++sp; }
+                        cur = h1 ? ((h2 && !firstNear) ? k2 : k1) : (h2 ? k2 : kNoNode);
                     }
                 }
             }
+            pt.ran(2, walkers);
             const uint32_t n_leaf = (uint32_t)__popcll(__ballot(at_leaf));
             const uint32_t n_walk = (uint32_t)__popcll(__ballot(in_bvh && !at_leaf));
             if (n_leaf != 0 && (n_leaf >= (uint32_t)RT_RAYS_LEAF_MIN_LANES || n_leaf >= n_walk)) {
+                const uint64_t parked = __ballot(at_leaf);
                 if (at_leaf) { // two triangles of the leaf per visit: six loads in flight together
                     const uint32_t off = leaf_data & 0x0FFFFFFFu;
                     const uint32_t cnt = ((leaf_data >> 28) & 7u) + 1;
@@ -236,11 +266,12 @@ __global__ __launch_bounds__(kBlock, RT_RAYS_MIN_WAVES) void k_rays(DScene S, IO
                         }
                     }
                     leaf_i += 2;
-                    if (stop) { sp = 0; at_leaf = false; }
+                    if (stop) { sp = 0; at_leaf = false; } // cur is kNoNode while parked
                     else if (leaf_i >= cnt) at_leaf = false;
                 }
+                pt.ran(3, parked);
             }
-            if (in_bvh && !at_leaf && sp == 0) { // mesh done: fold its result into the ray's (main.cpp:38-48 / 80-85)
+            if (in_bvh && !at_leaf && cur == kNoNode && sp == 0) { // mesh done: fold its result into the ray's (main.cpp:38-48 / 80-85)
                 in_bvh = false;
                 if (any_hit) {
                     if (m_hit) shadow_done(true);

@@ -741,6 +741,7 @@ int rt_trace_brief(rt_ctx *ctx, const float *rays6, const float *t_max, int n, r
     c = rt_counters{};
     c.closest_rays = dc.closest; c.shadow_rays = dc.shadow; c.box_tests = dc.box_tests; c.tri_tests = dc.tri_tests;
     c.kernel_ms = ms; c.trace_kernel_ms = ms; c.trace_launches = 1;
+    for (int i = 0; i < 16; ++i) c.phase_cycles[i] = dc.phase[i];
     for (int i = 0; i < n; ++i) {
         rt_hit_brief &o = out[i];
         if (t_max) { o = rt_hit_brief{0.0f, h[i].x != 0.0f ? 1 : 0, 0u, 0, 0.0f, 0.0f}; continue; }

@@ -79,6 +79,13 @@ def main():
             if name == args.only:
                 got, ms = timed(ctx.trace_brief, rays, tm)
                 print(f"{name:7s} ray-list {len(rays) / ms / 1e6:8.3f} Grays/s ({ms:7.2f} ms)")
+                ph = list(ctx.counters().phase_cycles)
+                if any(ph):
+                    tot = sum(ph[0:4]) + ph[12]
+                    for i, nm in enumerate(("refill", "scene", "walk", "leaf")):
+                        print(f"   {nm:7s} {100 * ph[i] / tot:5.1f} % of wave time, {ph[4 + i]:10d} executions, "
+                              f"{ph[8 + i] / max(1, ph[4 + i]):5.1f} lanes, {ph[i] / max(1, ph[4 + i]) * 10:7.0f} ns each")
+                    print(f"   other   {100 * ph[12] / tot:5.1f} %")
             continue
         if tm is None:
             ref, ms_ref = timed(ctx.trace, rays)
