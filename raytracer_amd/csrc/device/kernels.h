@@ -38,8 +38,8 @@ static_assert(kBlock == (int)kStackStride, "stack[level][thread] layout assumes 
 RT_DEV LaneStack lane_stack(uint32_t *lds, const DScene &S)
 {
     LaneStack st;
-    st.lds = (LdsStackPtr)lds + threadIdx.x;
-    st.ovf = (GlobalStackPtr)S.stack_overflow + ((size_t)blockIdx.x * kBlock + threadIdx.x);
+    st.lds = (LdsStackPtr)(u32x2 *)lds + threadIdx.x;
+    st.ovf = (GlobalStackPtr)(u32x2 *)S.stack_overflow + ((size_t)blockIdx.x * kBlock + threadIdx.x);
     st.lds_levels = (uint32_t)S.lds_levels;
     st.ovf_stride = gridDim.x * kBlock;
     return st;

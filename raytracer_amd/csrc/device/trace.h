@@ -35,12 +35,17 @@ struct Hit {
 // exactly once, whatever level each lane is at); deeper entries, which are rare, go
 // to a global overflow array laid out the same way.
 constexpr uint32_t kStackStride = 256;
-// The two homes of the stack are named by address space, so the compiler emits ds_read/ds_write
-// and global_load/global_store; through generic pointers it would emit flat instructions, which
-// take the slower path and wait on two counters.
+// The stack is reached through generic pointers (flat instructions).  Naming the two address spaces
+// (RT_STACK_TYPED: ds_read/ds_write for the LDS levels, global_load/store for the overflow) looks like
+// the obvious thing to do but measured 2-4 % slower in every kernel here, so it stays a switch.
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+#ifdef RT_STACK_TYPED
 typedef __attribute__((address_space(3))) u32x2 *LdsStackPtr;
 typedef __attribute__((address_space(1))) u32x2 *GlobalStackPtr;
+#else
+typedef u32x2 *LdsStackPtr;
+typedef u32x2 *GlobalStackPtr;
+#endif
 struct LaneStack {
     LdsStackPtr lds;     // &entries[threadIdx.x]
     GlobalStackPtr ovf;  // &overflow[global thread id]

@@ -71,40 +71,17 @@ RT_DEV uint32_t pack_meta(int bounce, int lobe, uint32_t status, bool has_contri
     return ((uint32_t)bounce & 0xFFFFu) | ((uint32_t)lobe << 16) | (status << 20) | ((has_contrib ? 1u : 0u) << 24);
 }
 
-// Work items are reserved by the workgroup, kLogicChunk at a time, and what a launch does not
-// use up stays with the workgroup for the next one (Q.block_items): the item counter sees one
-// atomic per chunk instead of one per wave and launch.  The grid must be the same in every launch.
-constexpr uint32_t kLogicChunk = 2048;
-
-__global__ __launch_bounds__(kBlock) void k_wf_logic(DScene S, DFrame F, const float *__restrict__ halton,
-                                                     const int32_t *__restrict__ active, uint64_t n_items, int k0, int nk,
-                                                     float4 *__restrict__ sbuf, FramePlanes out, WfPool P, WfQueue Q,
-                                                     DCounters *ctr, int first_call)
+// Steps 1 and 2 of a slot's turn: add the pending next-event estimate, shade the new closest hit
+// (src/main.cpp:173-264) and leave the next rays in the slot.  Returns the slot's status afterwards
+// (WF_EMPTY: the path, if there was one, has ended and its radiance is in the sample buffer).
+RT_DEV uint32_t wf_shade_slot(const DScene &S, const DFrame &F, const WfPool &P, uint32_t slot, uint4 &meta, float4 *sbuf,
+                              const FramePlanes &out, bool &want_ext, bool &want_shadow)
 {
-    __shared__ uint32_t s_wave[kBlock / 64];
-    __shared__ unsigned long long s_r0, s_r1;
-    __shared__ uint32_t s_l0, s_l1;
     const rt_light &light = S.lights[0];
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    // thread 0 keeps the workgroup's reserved item range [c_next, c_end)
-    unsigned long long c_next = 0, c_end = 0;
-    if (threadIdx.x == 0 && !first_call) { c_next = Q.block_items[blockIdx.x * 2]; c_end = Q.block_items[blockIdx.x * 2 + 1]; }
-    uint32_t new_paths = 0, n_alive = 0;
-
-    for (uint32_t base = blockIdx.x * kBlock; base < P.n_slots; base += gridDim.x * kBlock) {
-    const uint32_t slot = base + threadIdx.x;
-    const bool in_pool = slot < P.n_slots;
-    uint32_t status = WF_EMPTY;
-    uint4 meta = make_uint4(0, 0, 0, 0);
+    uint32_t status = (meta.y >> 20) & 0xFu;
     PathState ps;
     path_begin(ps, Ray{mk(0, 0, 0), mk(0, 0, 1)});
     ps.rng.state = 0; ps.rng.inc = 1;
-    bool want_ext = false, want_shadow = false;
-
-    if (in_pool && !first_call) {
-        meta = P.meta[slot];
-        status = (meta.y >> 20) & 0xFu;
-    }
     if (status != WF_EMPTY) {
         const float4 thr = P.thr[slot], res = P.res[slot];
         ps.throughput = mk(thr.x, thr.y, thr.z); ps.lastProb = thr.w;
@@ -211,6 +188,74 @@ __global__ __launch_bounds__(kBlock) void k_wf_logic(DScene S, DFrame F, const f
         }
     }
 
+    return status;
+}
+
+// Step 3 for one slot: start the camera path of work item `item` (src/main.cpp:294-323) in it.
+RT_DEV uint32_t wf_start_slot(const DFrame &F, const WfPool &P, uint32_t slot, uint64_t item, const float *halton,
+                          const int32_t *active, int k0, int nk, float4 *sbuf, uint4 &meta, bool &want_ext)
+{
+    uint32_t status;
+    PathState ps;
+    const uint32_t a = (uint32_t)(item / (uint32_t)nk);
+    const int k = k0 + (int)(item - (uint64_t)a * (uint32_t)nk);
+    const int pix = active[a];
+    const int i = pix % F.width, j = pix / F.width;
+    const uint64_t seed = pixel_seed(F.seed, (uint64_t)pix);
+    rng_set_sequence(ps.rng, 0, seed);
+    float off[4];
+    off[0] = rng_float(ps.rng); off[1] = rng_float(ps.rng); off[2] = rng_float(ps.rng); off[3] = rng_float(ps.rng);
+    rng_set_sequence(ps.rng, (uint64_t)k + 1, seed);
+    const Ray ray = camera_ray(F, halton, i, j, k, off);
+    status = F.max_bounces > 0 ? WF_ALIVE : WF_PROBE;
+    if (status == WF_PROBE && k != 0) {
+        sbuf[item] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); // no bounce, no plane to fill: done
+        status = WF_EMPTY;
+    } else {
+        P.ray_o[slot] = make_float4(ray.p.x, ray.p.y, ray.p.z, 0.0f);
+        P.ray_d[slot] = make_float4(ray.d.x, ray.d.y, ray.d.z, 0.0f);
+        P.thr[slot] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+        P.res[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        P.rng[slot] = make_uint2((uint32_t)ps.rng.state, (uint32_t)(ps.rng.state >> 32));
+        want_ext = true;
+    }
+    meta = make_uint4((uint32_t)item, pack_meta(0, LOBE_NONE, status, false), (uint32_t)pix, (uint32_t)k);
+    P.meta[slot] = meta;
+    return status;
+}
+
+// Work items are reserved by the workgroup, kLogicChunk at a time, and what a launch does not
+// use up stays with the workgroup for the next one (Q.block_items): the item counter sees one
+// atomic per chunk instead of one per wave and launch.  The grid must be the same in every launch.
+constexpr uint32_t kLogicChunk = 2048;
+
+__global__ __launch_bounds__(kBlock) void k_wf_logic(DScene S, DFrame F, const float *__restrict__ halton,
+                                                     const int32_t *__restrict__ active, uint64_t n_items, int k0, int nk,
+                                                     float4 *__restrict__ sbuf, FramePlanes out, WfPool P, WfQueue Q,
+                                                     DCounters *ctr, int first_call)
+{
+    __shared__ uint32_t s_wave[kBlock / 64];
+    __shared__ unsigned long long s_r0, s_r1;
+    __shared__ uint32_t s_l0, s_l1;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    // thread 0 keeps the workgroup's reserved item range [c_next, c_end)
+    unsigned long long c_next = 0, c_end = 0;
+    if (threadIdx.x == 0 && !first_call) { c_next = Q.block_items[blockIdx.x * 2]; c_end = Q.block_items[blockIdx.x * 2 + 1]; }
+    uint32_t new_paths = 0, n_alive = 0;
+
+    for (uint32_t base = blockIdx.x * kBlock; base < P.n_slots; base += gridDim.x * kBlock) {
+    const uint32_t slot = base + threadIdx.x;
+    const bool in_pool = slot < P.n_slots;
+    uint32_t status = WF_EMPTY;
+    uint4 meta = make_uint4(0, 0, 0, 0);
+    bool want_ext = false, want_shadow = false;
+
+    if (in_pool && !first_call) {
+        meta = P.meta[slot];
+        status = (meta.y >> 20) & 0xFu;
+    }
+    if (status != WF_EMPTY) status = wf_shade_slot(S, F, P, slot, meta, sbuf, out, want_ext, want_shadow);
+
     // 3. refill: finished and never-used slots take the next work items; the workgroup's requests are
     //    numbered through, served from what is left of its reserved range and then from a fresh chunk
     {
@@ -242,30 +287,7 @@ __global__ __launch_bounds__(kBlock) void k_wf_logic(DScene S, DFrame F, const f
             if (idx < s_l0) item = s_r0 + idx;
             else if (idx - s_l0 < s_l1) item = s_r1 + (idx - s_l0);
             if (need && item < n_items) {
-                const uint32_t a = (uint32_t)(item / (uint32_t)nk);
-                const int k = k0 + (int)(item - (uint64_t)a * (uint32_t)nk);
-                const int pix = active[a];
-                const int i = pix % F.width, j = pix / F.width;
-                const uint64_t seed = pixel_seed(F.seed, (uint64_t)pix);
-                rng_set_sequence(ps.rng, 0, seed);
-                float off[4];
-                off[0] = rng_float(ps.rng); off[1] = rng_float(ps.rng); off[2] = rng_float(ps.rng); off[3] = rng_float(ps.rng);
-                rng_set_sequence(ps.rng, (uint64_t)k + 1, seed);
-                const Ray ray = camera_ray(F, halton, i, j, k, off);
-                status = F.max_bounces > 0 ? WF_ALIVE : WF_PROBE;
-                if (status == WF_PROBE && k != 0) {
-                    sbuf[item] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); // no bounce, no plane to fill: done
-                    status = WF_EMPTY;
-                } else {
-                    P.ray_o[slot] = make_float4(ray.p.x, ray.p.y, ray.p.z, 0.0f);
-                    P.ray_d[slot] = make_float4(ray.d.x, ray.d.y, ray.d.z, 0.0f);
-                    P.thr[slot] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-                    P.res[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                    P.rng[slot] = make_uint2((uint32_t)ps.rng.state, (uint32_t)(ps.rng.state >> 32));
-                    want_ext = true;
-                }
-                meta = make_uint4((uint32_t)item, pack_meta(0, LOBE_NONE, status, false), (uint32_t)pix, (uint32_t)k);
-                P.meta[slot] = meta;
+                status = wf_start_slot(F, P, slot, item, halton, active, k0, nk, sbuf, meta, want_ext);
                 ++new_paths;
             } else if (need) {
                 meta.y = pack_meta(0, 0, WF_EMPTY, false);

@@ -1,8 +1,6 @@
 // C ABI of the GPU backend: context, scene upload, frame rendering, batch queries.
 // Host-side control only; the arithmetic lives in device/*.h.
-#include "device/wavefront.h"
 #include "device/pathsm.h"
-#include "device/rays.h"
 #include "rt_mi355x.h"
 
 #include <algorithm>
@@ -62,8 +60,12 @@ struct rt_ctx {
     DeviceBuf d_stack_ovf;
     // wavefront pipeline: path pool, ray queue, counters {count, alive, pad, pad, head(u64), item(u64)}
     DeviceBuf d_pool, d_wq_ctr;
-    uint32_t pool_slots = 0;
-    uint32_t pool_max = 1u << 22;
+    static constexpr int kMaxPools = 4;
+    hipStream_t pool_stream[kMaxPools] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t pool_event[kMaxPools] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t fork_event = nullptr;
+    int n_pools = 1;              // RT_POOLS: independent path pools in flight, each on its own stream (more were slower)
+    uint32_t pool_max = 1u << 22; // RT_POOL: slots per pool
     bool use_wavefront = false; // RT_PIPELINE=wave: separate logic / ray-queue kernels
     bool use_lockstep = true;   // RT_PIPELINE=mega: one whole trace call per lane in lock-step (k_paths); sm: k_path_sm
     size_t ovf_threads = 0;
@@ -185,62 +187,110 @@ size_t stack_lds_bytes(const DScene &S) { return (size_t)S.lds_levels * kBlock *
 
 } // namespace
 
-// One launch range through the wavefront pipeline: alternate k_wf_logic (shade, leave rays in
-// the slots, refill) and k_rays over the pool until no slot holds a path.  The host looks at the
-// alive count only every few rounds; a round on a pool that has emptied meanwhile does nothing.
-static int render_wavefront(rt_ctx *ctx, const DFrame &F, const int32_t *act, uint64_t items, int k0, int nk,
-                            const FramePlanes &planes, size_t lds)
+// Path pool with one slot per thread of the path kernel's grid.
+static int lane_pool(rt_ctx *ctx, uint32_t slots, WfPool &P)
 {
-    hipStream_t s = ctx->stream;
-    const uint32_t slots = (uint32_t)std::min<uint64_t>(ctx->pool_max, (items + kBlock - 1) / kBlock * kBlock);
-    // pool arrays, 256-byte aligned sub-allocations of one buffer
     const size_t sizes[13] = {16, 16, 16, 16, 8, 16, 16, 8, 16, 16, 16, 4, 4};
     size_t offs[13], total = 0;
     for (int i = 0; i < 13; ++i) { offs[i] = total; total += ((size_t)slots * sizes[i] + 255) / 256 * 256; }
     HIP_TRY(ctx, ctx->d_pool.reserve(total));
-    const dim3 logic_grid((unsigned)std::min<uint64_t>(slots / kBlock, (uint64_t)ctx->n_cu * 6));
-    HIP_TRY(ctx, ctx->d_wq_ctr.reserve(64 + (size_t)logic_grid.x * 16));
     char *base = ctx->d_pool.as<char>();
-    WfPool P{};
     P.ray_o = (float4 *)(base + offs[0]); P.ray_d = (float4 *)(base + offs[1]); P.thr = (float4 *)(base + offs[2]);
     P.res = (float4 *)(base + offs[3]); P.rng = (uint2 *)(base + offs[4]); P.meta = (uint4 *)(base + offs[5]);
     P.hit = (float4 *)(base + offs[6]); P.hit_uv = (float2 *)(base + offs[7]); P.sh_o = (float4 *)(base + offs[8]);
     P.sh_d = (float4 *)(base + offs[9]); P.contrib = (float4 *)(base + offs[10]); P.vis = (uint32_t *)(base + offs[11]);
     P.flags = (uint32_t *)(base + offs[12]);
     P.n_slots = slots;
-    char *cb = ctx->d_wq_ctr.as<char>();
-    WfQueue Q{};
-    Q.alive = (uint32_t *)cb; Q.item = (unsigned long long *)(cb + 8); Q.block_items = (unsigned long long *)(cb + 64);
+    return RT_OK;
+}
+
+// One launch range through the wavefront pipeline.  A pool alternates k_wf_logic (shade, leave rays
+// in the slots, refill from the shared item counter) and k_rays over its slots until none of its
+// slots holds a path.  Several pools run side by side on streams of their own: a ray kernel ends
+// with a tail in which a few long rays keep a few waves busy, and the other pools' kernels fill
+// the machine meanwhile.  The host looks at the alive counts only every few rounds; a round on a
+// pool that has emptied meanwhile does nothing.
+static int render_wavefront(rt_ctx *ctx, const DFrame &F, const int32_t *act, uint64_t items, int k0, int nk,
+                            const FramePlanes &planes, size_t lds)
+{
+    hipStream_t s = ctx->stream;
+    const int np = (int)std::min<uint64_t>((uint64_t)ctx->n_pools, std::max<uint64_t>(1, items / (4 * kBlock)));
+    const uint32_t slots = (uint32_t)std::min<uint64_t>(ctx->pool_max, ((items + np - 1) / np + kBlock - 1) / kBlock * kBlock);
+    // pool arrays, 256-byte aligned sub-allocations of one buffer
+    const size_t sizes[13] = {16, 16, 16, 16, 8, 16, 16, 8, 16, 16, 16, 4, 4};
+    size_t offs[13], total = 0;
+    for (int i = 0; i < 13; ++i) { offs[i] = total; total += ((size_t)slots * sizes[i] + 255) / 256 * 256; }
+    HIP_TRY(ctx, ctx->d_pool.reserve(total * np));
+    const dim3 logic_grid((unsigned)std::min<uint64_t>(slots / kBlock, (uint64_t)ctx->n_cu * 6));
+    const size_t ctr_bytes = (64 + (size_t)logic_grid.x * 16 + 255) / 256 * 256; // alive, trace queue word, per-workgroup item ranges
+    HIP_TRY(ctx, ctx->d_wq_ctr.reserve(256 + ctr_bytes * np));
+    unsigned long long *item_counter = ctx->d_wq_ctr.as<unsigned long long>();
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_wq_ctr.p, 0, 256 + ctr_bytes * np, s));
 
     const void *fn = wf_trace_kernel(ctx->counting, ctx->ray_levels);
     int per_cu = 1;
     HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kBlock, lds));
     per_cu = std::max(1, std::min(per_cu, 8));
     const dim3 trace_grid((unsigned)std::min<uint64_t>((uint64_t)ctx->n_cu * per_cu, (2ull * slots + kBlock - 1) / kBlock));
+    const size_t ovf_stride = std::max<size_t>(1, (size_t)(ctx->scene.stack_levels - ctx->scene.lds_levels)) * ctx->ovf_threads;
 
-    HIP_TRY(ctx, hipMemsetAsync(cb, 0, 16, s));
-    DScene a_scene = ctx->scene;
-    PoolIO a_io{P};
+    struct Pool { WfPool P; WfQueue Q; char *cb; DScene scene; bool done; uint32_t alive; };
+    Pool pool[rt_ctx::kMaxPools];
+    for (int p = 0; p < np; ++p) {
+        char *base = ctx->d_pool.as<char>() + total * p;
+        WfPool &P = pool[p].P;
+        P.ray_o = (float4 *)(base + offs[0]); P.ray_d = (float4 *)(base + offs[1]); P.thr = (float4 *)(base + offs[2]);
+        P.res = (float4 *)(base + offs[3]); P.rng = (uint2 *)(base + offs[4]); P.meta = (uint4 *)(base + offs[5]);
+        P.hit = (float4 *)(base + offs[6]); P.hit_uv = (float2 *)(base + offs[7]); P.sh_o = (float4 *)(base + offs[8]);
+        P.sh_d = (float4 *)(base + offs[9]); P.contrib = (float4 *)(base + offs[10]); P.vis = (uint32_t *)(base + offs[11]);
+        P.flags = (uint32_t *)(base + offs[12]);
+        P.n_slots = slots;
+        pool[p].cb = ctx->d_wq_ctr.as<char>() + 256 + ctr_bytes * p;
+        pool[p].Q.alive = (uint32_t *)pool[p].cb;
+        pool[p].Q.item = item_counter;
+        pool[p].Q.block_items = (unsigned long long *)(pool[p].cb + 64);
+        pool[p].scene = ctx->scene;
+        pool[p].scene.stack_overflow = ctx->scene.stack_overflow + ovf_stride * p; // ray kernels of different pools overlap in time
+        pool[p].done = false;
+        pool[p].alive = 0;
+    }
+    // the pools' streams start after what the frame's stream has queued so far
+    HIP_TRY(ctx, hipEventRecord(ctx->fork_event, s));
+    for (int p = 0; p < np; ++p) HIP_TRY(ctx, hipStreamWaitEvent(ctx->pool_stream[p], ctx->fork_event, 0));
+
     uint32_t a_n = 2 * slots;
     DCounters *a_ctr = ctx->d_counters.as<DCounters>();
-    unsigned long long *a_queue = ctx->d_queue.as<unsigned long long>();
-    void *targs[] = {&a_scene, &a_io, &a_n, &a_ctr, &a_queue};
     const uint32_t check_every = 8;
-    int first = 1;
     for (uint32_t iter = 0;; ++iter) {
-        HIP_TRY(ctx, hipMemsetAsync(cb, 0, 4, s)); // alive; the item counter runs on
-        HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue.p, 0, kQueueBytes, s));
-        hipLaunchKernelGGL(k_wf_logic, logic_grid, dim3(kBlock), 0, s, ctx->scene, F, ctx->d_halton.as<float>(), act, items, k0, nk,
-                           ctx->d_sbuf.as<float4>(), planes, P, Q, a_ctr, first);
-        HIP_TRY(ctx, hipGetLastError());
-        first = 0;
-        HIP_TRY(ctx, hipLaunchKernel(fn, trace_grid, dim3(kBlock), targs, lds, s));
+        for (int p = 0; p < np; ++p) {
+            if (pool[p].done) continue;
+            hipStream_t ps = ctx->pool_stream[p];
+            HIP_TRY(ctx, hipMemsetAsync(pool[p].cb, 0, 16, ps)); // alive and the ray kernel's queue word; the item counter runs on
+            hipLaunchKernelGGL(k_wf_logic, logic_grid, dim3(kBlock), 0, ps, pool[p].scene, F, ctx->d_halton.as<float>(), act, items, k0, nk,
+                               ctx->d_sbuf.as<float4>(), planes, pool[p].P, pool[p].Q, a_ctr, iter == 0 ? 1 : 0);
+            HIP_TRY(ctx, hipGetLastError());
+            PoolIO a_io{pool[p].P};
+            unsigned long long *a_queue = (unsigned long long *)(pool[p].cb + 8);
+            void *targs[] = {&pool[p].scene, &a_io, &a_n, &a_ctr, &a_queue};
+            HIP_TRY(ctx, hipLaunchKernel(fn, trace_grid, dim3(kBlock), targs, lds, ps));
+        }
         if (iter % check_every != check_every - 1) continue;
-        uint32_t alive = 0;
-        HIP_TRY(ctx, hipMemcpyAsync(&alive, cb, sizeof alive, hipMemcpyDeviceToHost, s));
-        HIP_TRY(ctx, hipStreamSynchronize(s));
-        if (alive == 0) break; // no slot holds a path any more
+        for (int p = 0; p < np; ++p)
+            if (!pool[p].done) HIP_TRY(ctx, hipMemcpyAsync(&pool[p].alive, pool[p].cb, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->pool_stream[p]));
+        bool all_done = true;
+        for (int p = 0; p < np; ++p) {
+            if (pool[p].done) continue;
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->pool_stream[p]));
+            if (pool[p].alive == 0) pool[p].done = true; // no slot holds a path and none could be refilled
+            else all_done = false;
+        }
+        if (all_done) break;
         if (iter > (1u << 24)) return ctx->fail(RT_ERR_HIP, "wavefront loop did not terminate");
+    }
+    // the frame's stream goes on after the pools
+    for (int p = 0; p < np; ++p) {
+        HIP_TRY(ctx, hipEventRecord(ctx->pool_event[p], ctx->pool_stream[p]));
+        HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->pool_event[p], 0));
     }
     return RT_OK;
 }
@@ -293,6 +343,12 @@ int rt_init(int device, rt_ctx **out)
         ctx->use_lockstep = strcmp(e3, "sm") != 0;
     }
     if (const char *e4 = getenv("RT_POOL")) ctx->pool_max = (uint32_t)std::max(256, atoi(e4));
+    if (const char *e5 = getenv("RT_POOLS")) ctx->n_pools = std::max(1, std::min((int)rt_ctx::kMaxPools, atoi(e5)));
+    for (int i = 0; i < rt_ctx::kMaxPools; ++i) {
+        if ((e = hipStreamCreateWithFlags(&ctx->pool_stream[i], hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+        if ((e = hipEventCreateWithFlags(&ctx->pool_event[i], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+    }
+    if ((e = hipEventCreateWithFlags(&ctx->fork_event, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     if (const char *e2 = getenv("RT_LDS_LEVELS")) ctx->lds_levels_max = std::max(1, std::min(64, atoi(e2))); // tuning knob
     if ((e = ctx->d_queue.reserve(kQueueBytes)) != hipSuccess) return bail("hipMalloc", e);
     *out = ctx;
@@ -304,6 +360,11 @@ void rt_shutdown(rt_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
+    for (int i = 0; i < rt_ctx::kMaxPools; ++i) {
+        if (ctx->pool_stream[i]) { (void)hipStreamSynchronize(ctx->pool_stream[i]); (void)hipStreamDestroy(ctx->pool_stream[i]); }
+        if (ctx->pool_event[i]) (void)hipEventDestroy(ctx->pool_event[i]);
+    }
+    if (ctx->fork_event) (void)hipEventDestroy(ctx->fork_event);
     for (hipEvent_t ev : {ctx->ev0, ctx->ev1, ctx->evk0, ctx->evk1}) if (ev) (void)hipEventDestroy(ev);
     delete ctx;
 }
@@ -433,7 +494,8 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc)
     S.lds_levels = std::min(S.stack_levels, ctx->lds_levels_max);
     const size_t ovf_levels = (size_t)(S.stack_levels - S.lds_levels);
     ctx->ovf_threads = (size_t)ctx->n_cu * 8 * kBlock;
-    HIP_TRY(ctx, ctx->d_stack_ovf.reserve(std::max<size_t>(1, ovf_levels) * ctx->ovf_threads * sizeof(uint2)));
+    // one area per kernel that can be in flight at a time (the wavefront pipeline runs one ray kernel per pool)
+    HIP_TRY(ctx, ctx->d_stack_ovf.reserve(std::max<size_t>(1, ovf_levels) * ctx->ovf_threads * sizeof(uint2) * rt_ctx::kMaxPools));
     S.stack_overflow = ctx->d_stack_ovf.as<uint2>();
 
     HIP_TRY(ctx, ctx->d_nodes.reserve(sizeof(DNode) * nn));
@@ -568,8 +630,15 @@ int rt_render(rt_ctx *ctx, const rt_render_params *prm, rt_frame_out *out)
                 float4 *a_sbuf = ctx->d_sbuf.as<float4>();
                 DCounters *a_ctr = ctx->d_counters.as<DCounters>();
                 unsigned long long *a_queue = ctx->d_queue.as<unsigned long long>();
-                void *args[] = {&a_scene, &F, &a_hal, &act, &a_items, &a_k0, &a_nk, &a_sbuf, &P, &a_ctr, &a_queue};
-                HIP_TRY(ctx, hipLaunchKernel(fn, grid, dim3(kBlock), args, lds, s));
+                if (ctx->use_lockstep) {
+                    void *args[] = {&a_scene, &F, &a_hal, &act, &a_items, &a_k0, &a_nk, &a_sbuf, &P, &a_ctr, &a_queue};
+                    HIP_TRY(ctx, hipLaunchKernel(fn, grid, dim3(kBlock), args, lds, s));
+                } else {
+                    WfPool pool;
+                    if (int rc = lane_pool(ctx, grid.x * kBlock, pool)) return rc;
+                    void *args[] = {&a_scene, &F, &a_hal, &act, &a_items, &a_k0, &a_nk, &a_sbuf, &P, &pool, &a_ctr, &a_queue};
+                    HIP_TRY(ctx, hipLaunchKernel(fn, grid, dim3(kBlock), args, lds, s));
+                }
             }
             }
             HIP_TRY(ctx, hipGetLastError());

@@ -54,6 +54,33 @@ def test_trace_queries_vs_reference(ctx, name):
     assert np.array_equal(occ, g["kat_flags"][:, 2]), "shadow rays"
 
 
+@pytest.mark.parametrize("name", ["kat_trace_a", "kat_trace_nested", "kat_trace_mesh"])
+def test_ray_list_kernel_vs_reference(ctx, name):
+    """rt_trace_brief (persistent ray-list kernel with ray-level regeneration) against the reference's answers."""
+    g = O.load_golden(name)
+    s = O.scene_from_golden(g)
+    ctx.upload(s.desc)
+    rays = np.tile(g["kat_rays"], (5, 1))  # more rays than lanes of a workgroup: lanes take several rays in turn
+    ref_id, ref_z = np.tile(g["kat_id"], 5), np.tile(g["kat_hit"][:, 0], 5)
+    got = ctx.trace_brief(rays)
+    assert np.array_equal(got["node"], ref_id), "hit node ids"
+    assert np.array_equal(bits(got["t"]), bits(ref_z)), "z"
+    ref_hit = np.tile(g["kat_flags"][:, 0].astype(bool), 5)
+    assert np.array_equal(got["front"][ref_hit], np.tile(g["kat_flags"][:, 1], 5)[ref_hit])
+    full = ctx.trace(rays)  # the brief answer is the winner the full query interpolates from
+    on_mesh = np.array([s.desc.nodes[i].prim == abi.RT_PRIM_MESH if i >= 0 else False for i in got["node"]])
+    if on_mesh.any():
+        assert (got["face"][on_mesh] < s.desc.meshes[0].nf).all()
+        w = 1.0 - got["u"][on_mesh] - got["v"][on_mesh]
+        assert (w >= -1e-6).all() and np.isfinite(full["n"][on_mesh]).all()
+    occ = ctx.trace_brief(rays, np.tile(g["kat_tmax"], 5))
+    assert np.array_equal(occ["node"], np.tile(g["kat_flags"][:, 2], 5)), "shadow rays"
+    c = ctx.counters()
+    assert c.shadow_rays == len(rays) and c.kernel_ms > 0
+    with pytest.raises(lib.RtError):
+        ctx.trace_brief(rays[:4], np.array([1.0, -1.0, 2.0, 3.0], np.float32))
+
+
 def test_path_radiance_vs_reference(ctx):
     g = O.load_golden("kat_paths_a")
     s = O.scene_from_golden(g)
@@ -130,11 +157,12 @@ def test_mesh_scene_vs_oracle_with_counters(ctx):
     assert abs(int(c.tri_tests) - int(cpu.stats.tri_tests)) <= 5e-3 * cpu.stats.tri_tests
 
 
-def test_wavefront_and_megakernel_pipelines_agree(monkeypatch):
-    """The ray-queue (wavefront) pipeline and the one-path-per-lane megakernel run the same
-    per-path arithmetic: every output plane and the ray counts must be identical."""
+def test_pipelines_agree(monkeypatch):
+    """The lock-step path kernel (default), the wavefront pipeline (logic kernel + ray-list kernel) and
+    the fused path kernel (ray-level regeneration in one launch) run the same per-path arithmetic:
+    every output plane and the ray counts must be identical."""
     ctxs = {}
-    for mode in ("mega", "wave"):
+    for mode in ("mega", "wave", "sm"):
         monkeypatch.setenv("RT_PIPELINE", mode)
         ctxs[mode] = lib.Context(0)
     monkeypatch.delenv("RT_PIPELINE")
@@ -148,10 +176,11 @@ def test_wavefront_and_megakernel_pipelines_agree(monkeypatch):
                 frames[mode] = render_gpu(c, s, prm, w, h)
                 k = c.counters()
                 counts[mode] = (k.closest_rays, k.shadow_rays, k.camera_paths)
-            for plane in ("rgb", "z", "sample_count", "object_id"):
-                assert np.array_equal(getattr(frames["mega"], plane), getattr(frames["wave"], plane)), (name, plane)
-            assert np.array_equal(bits(frames["mega"].linear), bits(frames["wave"].linear)), name
-            assert counts["mega"] == counts["wave"], name
+            for other in ("wave", "sm"):
+                for plane in ("rgb", "z", "sample_count", "object_id"):
+                    assert np.array_equal(getattr(frames["mega"], plane), getattr(frames[other], plane)), (name, other, plane)
+                assert np.array_equal(bits(frames["mega"].linear), bits(frames[other].linear)), (name, other)
+                assert counts["mega"] == counts[other], (name, other)
     finally:
         for c in ctxs.values():
             c.close()
