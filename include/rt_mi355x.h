@@ -129,7 +129,13 @@ typedef struct rt_camera {
     int32_t srgb;
 } rt_camera;
 
-typedef enum rt_mode { RT_MODE_PATH = 0 } rt_mode;
+/* RT_MODE_PATH:    the path tracer of the reference at HEAD (src/main.cpp:160-268).
+ * RT_MODE_WHITTED: the Whitted-style shader of the reference's project-12 snapshot (project12.zip,
+ *                  src/materials.cpp:14-202, src/lights.h:69-108, src/main.cpp:132-270) without photon
+ *                  maps: Blinn-Phong direct light with the adaptive 4..64-ray soft shadows of
+ *                  PointLight::Illuminate, then - while bounce < max_bounces (the snapshot compiles in 5) -
+ *                  one Monte-Carlo indirect ray on the first two bounces, glossy reflection and refraction. */
+typedef enum rt_mode { RT_MODE_PATH = 0, RT_MODE_WHITTED = 1 } rt_mode;
 
 /* Everything the reference fixes at compile time (src/main.cpp:93,107,164,
  * 220-221,262,273-274,369) plus the seeding convention and the tile shard. */

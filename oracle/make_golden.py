@@ -8,6 +8,7 @@ seeds, generated scene text) and the reference's outputs for them - no
 reference source text.
 
     python oracle/make_golden.py            # regenerate everything
+    python oracle/make_golden.py --whitted  # only the project-12 (Whitted-style shader) fixtures
 """
 import os
 import subprocess
@@ -22,14 +23,15 @@ sys.path.insert(0, ROOT)
 from raytracer_amd import scenes  # noqa: E402
 
 HARNESS = os.path.join(HERE, "_ref", "ref_harness")
+HARNESS_P12 = os.path.join(HERE, "_ref", "ref_harness_p12")  # the project-12 snapshot (Whitted-style shader)
 REF_SCENE = "/root/reference/assets/scene.xml"
 GOLD = os.path.join(ROOT, "tests", "golden")
 
 
-def run(scene, cmd, *args, cwd=None):
+def run(scene, cmd, *args, cwd=None, harness=None):
     """Run one harness command, return {name: array}."""
     with tempfile.TemporaryDirectory() as out:
-        subprocess.run([HARNESS, scene, out, cmd] + [str(a) for a in args], check=True, cwd=cwd,
+        subprocess.run([harness or HARNESS, scene, out, cmd] + [str(a) for a in args], check=True, cwd=cwd,
                        stdout=subprocess.DEVNULL)
         res = {}
         with open(os.path.join(out, "manifest.txt")) as fp:
@@ -46,13 +48,44 @@ def save(name, **arrays):
     print("%-32s %7.1f KB" % (name + ".npz", os.path.getsize(path) / 1024))
 
 
-def scene_bundle(scene, cwd=None):
-    d = run(scene, "scene", cwd=cwd)
+def scene_bundle(scene, cwd=None, harness=None):
+    d = run(scene, "scene", cwd=cwd, harness=harness)
     return {"scene_" + k: v for k, v in d.items()}
+
+
+def whitted():
+    """Images of the project-12 snapshot's Whitted-style shader (no photon maps).
+    params = seed, min spp, max spp, width, height, max_bounces."""
+    if not os.path.exists(HARNESS_P12):
+        sys.exit("build the snapshot harness first: make -C oracle ref12")
+    H = HARNESS_P12
+
+    def image(name, scene, bundle, seed, mn, mx, delta, w, h, bounces, cwd=None, **extra):
+        img = run(scene, "render_whitted", seed, mn, mx, delta, w, h, bounces, cwd=cwd, harness=H)
+        save(name, **bundle, **extra, params=np.array([seed, mn, mx, w, h, bounces], np.int64), delta=np.float32(delta), **img)
+
+    sa = scene_bundle(REF_SCENE, harness=H)
+    image("whitted_a_96x54_b0", REF_SCENE, sa, 7, 4, 4, 0.01, 96, 54, 0)
+    image("whitted_a_96x54_b5", REF_SCENE, sa, 7, 4, 4, 0.01, 96, 54, 5)
+    image("whitted_a_64x36_adaptive", REF_SCENE, sa, 3, 4, 16, 0.05, 64, 36, 5)
+    with tempfile.TemporaryDirectory() as tmp:
+        xml = scenes.spheres_scene_xml(seed=1001, grid=4, width=96, height=54)
+        p = os.path.join(tmp, "spheres.xml")
+        open(p, "w").write(xml)
+        image("whitted_spheres_96x54_b0", p, scene_bundle(p, harness=H), 7, 8, 8, 0.01, 96, 54, 0,
+              xml=np.frombuffer(xml.encode(), np.uint8))
+        mesh = scenes.heightfield(nx=32, ny=16)
+        scenes.write_obj(os.path.join(tmp, "mesh_small.obj"), mesh)
+        xml = scenes.mesh_scene_xml("mesh_small.obj", width=96, height=54)
+        p = os.path.join(tmp, "mesh.xml")
+        open(p, "w").write(xml)
+        image("whitted_mesh_96x54_b5", p, scene_bundle(p, cwd=tmp, harness=H), 7, 4, 4, 0.01, 96, 54, 5, cwd=tmp)
 
 
 def main():
     os.makedirs(GOLD, exist_ok=True)
+    if "--whitted" in sys.argv:  # only the snapshot's fixtures
+        return whitted()
     if not os.path.exists(HARNESS):
         sys.exit("build the harness first: make -C oracle ref")
 
@@ -101,6 +134,7 @@ def main():
         save("kat_trace_mesh", **small, **run(p, "kat_trace", 4096, 31, 40, cwd=tmp))
         img = run(p, "render", 7, 8, 8, 0.01, 96, 54, cwd=tmp)
         save("image_mesh_96x54_s8", **small, params=np.array([7, 8, 8, 96, 54], np.int64), delta=np.float32(0.01), **img)
+    whitted()
 
 
 if __name__ == "__main__":

@@ -10,6 +10,11 @@
 //
 // Built only where /root/reference exists (see oracle/Makefile, target `ref`),
 // output goes to oracle/_ref/ which is git-ignored.
+//
+// With -DREF_P12 the same file is compiled against the project-12 snapshot of the
+// reference (project12.zip, unpacked to a temporary directory by `make ref12`): the
+// snapshot has the Whitted-style shader instead of the path tracer, so the path
+// commands are left out and `render_whitted` is added.
 
 #include <chrono>
 #include <ostream>
@@ -26,6 +31,7 @@ std::ostream &operator<<(std::ostream &os, std::chrono::duration<R, P> const &d)
 #undef main
 
 #include "objects.h"
+#include "materials.h" // the snapshot's main.cpp does not pull it in
 
 #include <cstdio>
 #include <cstdlib>
@@ -231,6 +237,103 @@ static inline uint64_t pixelSeed(uint64_t frameSeed, uint64_t pixelIndex)
     return frameSeed + pixelIndex * 0x9E3779B97F4A7C15ULL;
 }
 
+#ifdef REF_P12
+// The snapshot's switches (its renderer.cpp, which the harness replaces): no photon maps.
+Renderer renderer;
+const bool doingDirectWithPhotonMapping{ false };
+const bool doingIndirectWithPhotonMapping{ false };
+const bool doingCaustics{ false };
+const bool monteCarloWithPhoton{ false };
+
+// CanBounce with a run-time limit.  The snapshot copies the ShadeInfo by value into a plain
+// ShadeInfo for every secondary ray, so below the camera ray its compiled-in limit of 5 is
+// back: only max_bounces 0 and 5 mean the same thing at every depth.
+static int g_maxBounces = 5;
+struct HarnessShadeInfo : public ShadeInfo {
+    using ShadeInfo::ShadeInfo;
+    bool CanBounce() const override { return bounce < g_maxBounces; }
+};
+
+// the pixel loop of the snapshot (its main.cpp:160-270) with the seeding convention of cmdRender
+static void cmdRenderWhitted(uint64_t seed, int minS, int maxS, float deltaMax, int W, int H, int maxBounces)
+{
+    g_maxBounces = maxBounces;
+    setupCamera(W, H);
+    flattenScene();
+    const Camera &cam = renderer.GetCamera();
+    W = cam.imgWidth; H = cam.imgHeight;
+    const size_t rows = (size_t)H;
+    std::vector<uint8_t> rgb(rows * W * 3);
+    std::vector<float> lin(rows * W * 3), z(rows * W);
+    std::vector<int32_t> cnt(rows * W), ids(rows * W);
+    for (int j = 0; j < H; ++j) {
+        for (int i = 0; i < W; ++i) {
+            const uint64_t ps = pixelSeed(seed, (uint64_t)j * W + i);
+            RNG &rng = tileThreads::rng;
+            rng.SetSequence(0, ps);
+            const float aaX = rng.RandomFloat();
+            const float aaY = rng.RandomFloat();
+            const float dofT = rng.RandomFloat();
+            const float dofR = rng.RandomFloat();
+            Color sum{ 0.0f }, sumSq{ 0.0f };
+            size_t n = 0;
+            const size_t o = (size_t)j * W + i;
+            for (int k = 0; k < maxS; ++k) {
+                ++n;
+                rng.SetSequence((uint64_t)k + 1, ps);
+                const float jx{ fmod(tileThreads::aaHaltonSeqX[k] + aaX, 1.0f) };
+                const float jy{ fmod(tileThreads::aaHaltonSeqY[k] + aaY, 1.0f) };
+                const float px{ static_cast<float>(i) + jx };
+                const float py{ static_cast<float>(j) + jy };
+                const float sx{ -tileThreads::imagePlaneHalfWidth + tileThreads::pixelSize * px };
+                const float sy{ tileThreads::imagePlaneHalfHeight - tileThreads::pixelSize * py };
+                const Vec3f dest{ cam.pos + tileThreads::cameraToWorld * Vec3f{ sx, sy, -cam.focaldist } };
+                const float jt{ fmod(tileThreads::diskHaltonSeqTheta[k] + dofT, 1.0f) };
+                const float jr{ fmod(tileThreads::diskHaltonSeqRadius[k] + dofR, 1.0f) };
+                const float diskTheta = jt * 2.0f * M_PI;
+                const float diskRadius{ sqrt(jr) };
+                const Vec3f off{ diskRadius * cam.dof * cos(diskTheta), diskRadius * cam.dof * sin(diskTheta), 0.0f };
+                const Vec3f org{ cam.pos + tileThreads::cameraToWorld * off };
+                const Ray ray{ org, dest - org };
+                HitInfo h{};
+                HarnessShadeInfo sInfo{ renderer.GetScene().lights, renderer.GetScene().environment, rng };
+                sInfo.SetPixelSample(i);
+                Color c;
+                const bool hit = renderer.TraceRay(ray, h);
+                if (k == 0) { ids[o] = nodeId(h, hit); z[o] = h.z; }
+                if (hit) {
+                    sInfo.SetHit(ray, h);
+                    c = h.light ? Color{ 1.0f, 1.0f, 1.0f } : h.node->GetMaterial()->Shade(sInfo);
+                } else {
+                    const float u{ (static_cast<float>(i) + tileThreads::aaHaltonSeqX[k]) / static_cast<float>(cam.imgWidth - 1) };
+                    const float v{ (static_cast<float>(j) + tileThreads::aaHaltonSeqY[k]) / static_cast<float>(cam.imgHeight - 1) };
+                    c = renderer.GetScene().background.Eval(Vec3f{ u, v, 1.0f });
+                }
+                sum += c;
+                sumSq += c * c;
+                if ((int)n < minS) continue;
+                Color sigma{ (sumSq - ((sum * sum) / static_cast<float>(n))) / (static_cast<float>(n - 1)) };
+                sigma.r = sqrtf(fmaxf(0.0f, sigma.r));
+                sigma.g = sqrtf(fmaxf(0.0f, sigma.g));
+                sigma.b = sqrtf(fmaxf(0.0f, sigma.b));
+                const Color delta{ 3.0f * (sigma / sqrtf(static_cast<float>(n))) };
+                if (delta.r < deltaMax && delta.g < deltaMax && delta.b < deltaMax) break;
+            }
+            Color c{ sum / static_cast<float>(n) };
+            lin[o * 3 + 0] = c.r; lin[o * 3 + 1] = c.g; lin[o * 3 + 2] = c.b;
+            if (cam.sRGB) c = c.Linear2sRGB();
+            const Color24 q{ c };
+            rgb[o * 3 + 0] = q.r; rgb[o * 3 + 1] = q.g; rgb[o * 3 + 2] = q.b;
+            cnt[o] = (int)n;
+        }
+    }
+    dumpB("rgb", rgb, {rows, (size_t)W, 3});
+    dumpF("linear", lin, {rows, (size_t)W, 3});
+    dumpF("z", z, {rows, (size_t)W});
+    dumpI("sample_count", cnt, {rows, (size_t)W});
+    dumpI("object_id", ids, {rows, (size_t)W});
+}
+#else
 static void cmdRender(uint64_t seed, int minS, int maxS, float deltaMax, int W, int H, int y0, int y1)
 {
     setupCamera(W, H);
@@ -305,6 +408,8 @@ static void cmdRender(uint64_t seed, int minS, int maxS, float deltaMax, int W, 
     dumpI("object_id", ids, {rows, (size_t)W});
 }
 
+#endif // REF_P12
+
 // -----------------------------------------------------------------------------
 // known-answer vectors
 // -----------------------------------------------------------------------------
@@ -364,6 +469,7 @@ static void cmdKatTrace(int n, uint64_t seed, float extent)
     dumpF("kat_hit", out, {(size_t)n, 12}); dumpI("kat_id", ids, {(size_t)n}); dumpI("kat_flags", flags, {(size_t)n, 3});
 }
 
+#ifndef REF_P12
 // sampler KATs: light and material GenerateSample / GetSampleInfo at synthetic surface points
 static void cmdKatSamplers(int n, uint64_t seed)
 {
@@ -449,6 +555,8 @@ static void cmdKatPaths(int n, uint64_t seed, float extent)
     dumpF("path_rays", rays, {(size_t)n, 6}); dumpF("path_radiance", rad, {(size_t)n, 3});
 }
 
+#endif // !REF_P12
+
 static void cmdTime(int threads)
 {
     // un-seeded, the reference's own thread pool and its compiled-in 128 spp
@@ -486,6 +594,11 @@ int main(int argc, char **argv)
     }
     auto A = [&](int i, const char *def) { return std::string(argc > i ? argv[i] : def); };
     if (cmd == "scene") cmdDumpScene();
+#ifdef REF_P12
+    else if (cmd == "render_whitted") // seed min max delta W H max_bounces
+        cmdRenderWhitted(strtoull(A(4, "7").c_str(), 0, 0), atoi(A(5, "16").c_str()), atoi(A(6, "16").c_str()), (float)atof(A(7, "0.01").c_str()),
+                         atoi(A(8, "0").c_str()), atoi(A(9, "0").c_str()), atoi(A(10, "5").c_str()));
+#else
     else if (cmd == "render")
         cmdRender(strtoull(A(4, "7").c_str(), 0, 0), atoi(A(5, "16").c_str()), atoi(A(6, "16").c_str()), (float)atof(A(7, "0.01").c_str()),
                   atoi(A(8, "0").c_str()), atoi(A(9, "0").c_str()), atoi(A(10, "0").c_str()), atoi(A(11, "0").c_str()));
@@ -493,6 +606,7 @@ int main(int argc, char **argv)
     else if (cmd == "kat_trace") cmdKatTrace(atoi(A(4, "4096").c_str()), strtoull(A(5, "1").c_str(), 0, 0), (float)atof(A(6, "40").c_str()));
     else if (cmd == "kat_samplers") cmdKatSamplers(atoi(A(4, "1024").c_str()), strtoull(A(5, "1").c_str(), 0, 0));
     else if (cmd == "kat_paths") cmdKatPaths(atoi(A(4, "4096").c_str()), strtoull(A(5, "1").c_str(), 0, 0), (float)atof(A(6, "40").c_str()));
+#endif
     else if (cmd == "time") cmdTime(atoi(A(4, "8").c_str()));
     else { fprintf(stderr, "unknown command %s\n", cmd.c_str()); return 1; }
     return 0;

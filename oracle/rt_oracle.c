@@ -830,6 +830,204 @@ void orc_trace_path(const rt_scene_desc *sc, const float ray6[6], orc_rng *rng,
 /* ------------------------------------------------------------------------- */
 /* camera + pixel loop (src/main.cpp:271-385,399-414)                        */
 /* ------------------------------------------------------------------------- */
+/* ------------------------------------------------------------------------- */
+/* Whitted-style shading of the project-12 snapshot (p12 = project12.zip)     */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+    const rt_scene_desc *sc;
+    const rt_render_params *prm;
+    const float (*halton)[64]; /* rows 0,1 = bases 2,3 (materials.cpp:10-11), rows 2,3 = bases 5,7 (lights.h:63-64) */
+    int p_sample;              /* SetPixelSample(i): the pixel's x coordinate (p12 main.cpp:214) */
+    orc_rng *rng;
+    orc_stats *st;
+} wctx;
+
+/* SamplerInfo::SetHit + what Shade reads from it (p12 renderer.h:146-154) */
+typedef struct { v3 p, n, v; int front; int bounce; } wshade;
+
+static v3 whitted_shade(const wctx *C, const wshade *s, const rt_material *m);
+
+/* ShadeInfo::TraceShadowRay(dir, t_max) (p12 main.cpp:126-130, renderer.h:184): 1 = unoccluded */
+static float w_shadow(const wctx *C, v3 p, v3 dir, float t_max)
+{
+    ray_t r;
+    r.p = vadd(p, vscale(dir, 0.0002f));
+    r.d = dir;
+    return trace_shadow(C->sc, r, t_max, C->st) ? 0.0f : 1.0f;
+}
+
+/* Light::Illuminate (p12 lights.h:33,49,69-108) */
+static v3 w_illuminate(const wctx *C, const rt_light *l, v3 P, v3 *dir)
+{
+    const v3 I = vld(l->intensity);
+    if (l->type == RT_LIGHT_AMBIENT) { *dir = V3(0, 0, 0); return I; }
+    if (l->type == RT_LIGHT_DIRECT) {
+        *dir = vneg(vld(l->direction));
+        return vscale(I, w_shadow(C, P, *dir, BIGFLOAT));
+    }
+    const v3 pos = vld(l->position);
+    const v3 d = vsub(pos, P);
+    const float distSquared = vlen2(d);
+    *dir = vnormalize(d);
+    v3 u, v;
+    orthonormals(*dir, &u, &v);
+    const float offsetX = orc_rng_float(C->rng);
+    const float offsetY = orc_rng_float(C->rng);
+    const int P16 = C->prm->halton_period;
+    size_t numHits = 0;
+    for (size_t i = 0; i < 64; ++i) {
+        const float jitterTheta = fmodf(offsetX + C->halton[2][i % (size_t)P16], 1.0f);
+        const float jitterRadius = fmodf(offsetY + C->halton[3][i % (size_t)P16], 1.0f);
+        const float diskTheta = (float)(jitterTheta * 2.0f * M_PI);
+        const float diskRadius = sqrtf(jitterRadius);
+        const float x = diskRadius * cosf(diskTheta);
+        const float y = diskRadius * sinf(diskTheta);
+        const v3 destination = vadd(vadd(pos, vscale(u, x * l->size)), vscale(v, y * l->size));
+        const v3 sampleRayDir = vsub(destination, P);
+        if (w_shadow(C, P, sampleRayDir, 1.0f) == 1.0f) ++numHits;
+        if (i + 1 == 4 && (numHits == 0 || numHits == 4))
+            return vdivs(vdivs(vscale(I, (float)numHits), (float)4), distSquared);
+    }
+    return vdivs(vdivs(vscale(I, (float)numHits), (float)64), distSquared);
+}
+
+/* TexturedColor::EvalEnvironment without a texture is the colour itself (scene.h:390-397) */
+static v3 w_environment(const wctx *C) { return vld(C->sc->environment); }
+
+/* ShadeInfo::TraceSecondaryRay (p12 main.cpp:132-155); the caller has checked CanBounce */
+static v3 w_secondary(const wctx *C, const wshade *from, ray_t ray, float *dist)
+{
+    hit_t h; hit_init(&h);
+    if (!trace_ray(C->sc, ray, &h, C->st)) { *dist = BIGFLOAT; return w_environment(C); }
+    *dist = h.z;
+    if (h.light) return V3(1.0f, 1.0f, 1.0f);
+    wshade s;
+    s.p = h.p; s.n = vnormalize(h.n); s.v = vneg(vnormalize(ray.d)); s.front = h.front; s.bounce = from->bounce + 1;
+    return whitted_shade(C, &s, &C->sc->materials[C->sc->nodes[h.node].material]);
+}
+
+/* (x u + y v) + z n with the reference's association (p12 materials.cpp:96,125,153) */
+static v3 w_frame(v3 u, v3 v, v3 n, float x, float y, float z) { return vadd(vadd(vscale(u, x), vscale(v, y)), vscale(n, z)); }
+
+/* MtlBlinn::Shade with all four photon-map switches off (p12 materials.cpp:14-202) */
+static v3 whitted_shade(const wctx *C, const wshade *s, const rt_material *m)
+{
+    const rt_scene_desc *sc = C->sc;
+    v3 final = vld(m->emission);
+    const v3 normal = vnormalize(s->n);
+    const v3 diffuseColor = vld(m->diffuse);
+    const v3 specular = vld(m->specular);
+    const float gloss = m->glossiness;
+    for (uint32_t i = 0; i < sc->n_lights; ++i) {
+        const rt_light *l = &sc->lights[i];
+        v3 lightDir;
+        const v3 lightIntensity = w_illuminate(C, l, s->p, &lightDir);
+        if (l->type == RT_LIGHT_AMBIENT) { final = vadd(final, vmul(diffuseColor, lightIntensity)); continue; }
+        const float geometryTerm = std_max(0.0f, vdot(normal, lightDir));
+        final = vadd(final, vscale(vmul(vscale(diffuseColor, (float)(1.0f / M_PI)), lightIntensity), geometryTerm));
+        const v3 halfway = vnormalize(vadd(s->v, lightDir));
+        const float blinnTerm = std_max(0.0f, vdot(normal, halfway));
+        const float k = (float)((gloss + 2.0f) / (8.0f * M_PI));
+        final = vadd(final, vscale(vmul(vscale(vscale(specular, k), powf(blinnTerm, gloss)), lightIntensity), geometryTerm));
+    }
+    if (!(s->bounce < C->prm->max_bounces)) return final; /* CanBounce (p12 renderer.h:180) */
+
+    const int ps = C->p_sample;
+    const int P16 = C->prm->halton_period;
+    /* Monte-Carlo indirect light, first two bounces (p12 materials.cpp:74-103) */
+    if ((diffuseColor.x + diffuseColor.y + diffuseColor.z) > 0.0f && s->bounce < 2) {
+        const float phiOffset = orc_rng_float(C->rng);
+        const float thetaOffset = orc_rng_float(C->rng);
+        const float phi = (float)(2.0f * M_PI * fmodf(C->halton[0][ps % P16] + phiOffset, 1.0f));
+        const float cosTheta = sqrtf(fmodf(C->halton[1][ps % P16] + thetaOffset, 1.0f));
+        const float sinTheta = sqrtf(1.0f - cosTheta * cosTheta);
+        const float x = sinTheta * cosf(phi), y = sinTheta * sinf(phi), z = cosTheta;
+        v3 u, v;
+        orthonormals(normal, &u, &v);
+        const v3 dir = w_frame(u, v, normal, x, y, z);
+        ray_t r; r.p = vadd(s->p, vscale(dir, 0.0002f)); r.d = dir;
+        float dist;
+        v3 colorSum = V3(0, 0, 0);
+        colorSum = vadd(colorSum, vmul(w_secondary(C, s, r, &dist), diffuseColor));
+        final = vadd(final, vdivs(colorSum, (float)1));
+    }
+    /* glossy reflection (p12 materials.cpp:106-133) */
+    const v3 reflection = vld(m->reflection);
+    if ((reflection.x + reflection.y + reflection.z) > 0.0f) {
+        const float phiOffset = orc_rng_float(C->rng);
+        const float thetaOffset = orc_rng_float(C->rng);
+        const float phi = (float)(2.0f * M_PI * fmodf(C->halton[0][ps % P16] + phiOffset, 1.0f));
+        const float cosTheta = powf(fmodf(C->halton[1][ps % P16] + thetaOffset, 1.0f), 1.0f / (gloss + 1.0f));
+        const float sinTheta = sqrtf(1.0f - cosTheta * cosTheta);
+        const float x = sinTheta * cosf(phi), y = sinTheta * sinf(phi), z = cosTheta;
+        v3 u, v;
+        orthonormals(normal, &u, &v);
+        const v3 h = w_frame(u, v, normal, x, y, z);
+        const v3 reflectionDir = vsub(vscale(vscale(h, 2), vdot(s->v, h)), s->v);
+        if (vdot(reflectionDir, normal) > 0.0f) {
+            ray_t r; r.p = vadd(s->p, vscale(reflectionDir, 0.0002f)); r.d = reflectionDir;
+            float dist;
+            final = vadd(final, vmul(w_secondary(C, s, r, &dist), reflection));
+        }
+    }
+    /* refraction (p12 materials.cpp:136-199) */
+    const v3 refraction = vld(m->refraction);
+    if ((refraction.x + refraction.y + refraction.z) > 0.0f) {
+        const float phiOffset = orc_rng_float(C->rng);
+        const float thetaOffset = orc_rng_float(C->rng);
+        const v3 N = s->front ? normal : vneg(normal);
+        v3 u, v;
+        orthonormals(N, &u, &v);
+        float dist;
+        const float phi = (float)(2.0f * M_PI * fmodf(C->halton[0][ps % P16] + phiOffset, 1.0f));
+        const float cosTheta = powf(fmodf(C->halton[1][ps % P16] + thetaOffset, 1.0f), 1.0f / (gloss + 1.0f));
+        const float sinTheta = sqrtf(1.0f - cosTheta * cosTheta);
+        const float x = sinTheta * cosf(phi), y = sinTheta * sinf(phi), z = cosTheta;
+        const v3 h = w_frame(u, v, N, x, y, z);
+        const float viewDotH = vdot(s->v, h);
+        const float ratio = s->front ? 1.0f / m->ior : m->ior;
+        /* pow(float, int) is the double overload: these three expressions run in double and are narrowed once */
+        const float cos2 = (float)(1.0f - pow((double)ratio, 2.0) * (1.0f - pow((double)viewDotH, 2.0)));
+        if (cos2 < 0.0f) { /* total internal reflection */
+            const v3 reflectionDir = vsub(vscale(vscale(h, 2), viewDotH), s->v);
+            if (vdot(reflectionDir, N) <= 0.0f) return final;
+            ray_t r; r.p = vadd(s->p, vscale(reflectionDir, 0.0002f)); r.d = reflectionDir;
+            return vadd(final, vmul(w_secondary(C, s, r, &dist), refraction));
+        }
+        const float fresnelRatio = (float)pow((double)((1 - m->ior) / (1 + m->ior)), 2.0);
+        const float F = (float)(fresnelRatio + (1 - fresnelRatio) * pow((double)(1 - viewDotH), 5.0));
+        v3 colorFromReflection = V3(0, 0, 0);
+        const v3 reflectionDir = vsub(vscale(vscale(h, 2), vdot(s->v, h)), s->v);
+        if (vdot(reflectionDir, N) > 0.0f) {
+            ray_t r; r.p = vadd(s->p, vscale(reflectionDir, 0.0002f)); r.d = reflectionDir;
+            colorFromReflection = vmul(w_secondary(C, s, r, &dist), refraction);
+        }
+        final = vadd(final, vscale(colorFromReflection, F));
+        const v3 refractionDir = vsub(vscale(s->v, -ratio), vscale(h, sqrtf(cos2) - ratio * viewDotH));
+        ray_t r; r.p = vadd(s->p, vscale(refractionDir, 0.0002f)); r.d = refractionDir;
+        v3 c = vmul(w_secondary(C, s, r, &dist), refraction);
+        c.x *= expf(-m->absorption[0] * dist);
+        c.y *= expf(-m->absorption[1] * dist);
+        c.z *= expf(-m->absorption[2] * dist);
+        final = vadd(final, vscale(c, 1.0f - F));
+    }
+    return final;
+}
+
+/* one sample of the p12 pixel loop after the camera ray has been built (p12 main.cpp:212-231) */
+static v3 whitted_sample(const rt_scene_desc *sc, const rt_render_params *prm, const float (*halton)[64], ray_t ray,
+                         int pixel_x, orc_rng *rng, orc_stats *st)
+{
+    wctx C = { sc, prm, halton, pixel_x, rng, st };
+    if (st) st->paths++;
+    hit_t h; hit_init(&h);
+    if (!trace_ray(sc, ray, &h, st)) return vld(sc->background); /* constant background: Eval(u,v,1) without a texture */
+    if (h.light) return V3(1.0f, 1.0f, 1.0f);
+    wshade s;
+    s.p = h.p; s.n = vnormalize(h.n); s.v = vneg(vnormalize(ray.d)); s.front = h.front; s.bounce = 0;
+    return whitted_shade(&C, &s, &sc->materials[sc->nodes[h.node].material]);
+}
+
 void orc_camera_derive(const rt_camera *cam, float out[12])
 {
     const v3 camZ = vneg(vnormalize(vld(cam->dir)));
@@ -916,7 +1114,8 @@ static void render_pixel(job_t *J, int i, int j, orc_stats *st)
             if (J->out->object_id) J->out->object_id[o] = hit ? h.node : -1;
         }
         v3 c;
-        trace_path(J->sc, ray, &rng, prm, &c, st);
+        if (prm->mode == RT_MODE_WHITTED) c = whitted_sample(J->sc, prm, (const float (*)[64])J->halton, ray, i, &rng, st);
+        else trace_path(J->sc, ray, &rng, prm, &c, st);
         sum = vadd(sum, c);
         sumSq = vadd(sumSq, vmul(c, c));
         if ((int)n < prm->min_spp) continue;

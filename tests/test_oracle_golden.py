@@ -146,3 +146,32 @@ def test_seeded_images(name):
     assert np.array_equal(fr.rgb, g["rgb"]), "8-bit image"
     if "adaptive" in name:
         assert len(np.unique(g["sample_count"])) > 3
+
+
+WHITTED = ["whitted_a_96x54_b0", "whitted_a_96x54_b5", "whitted_a_64x36_adaptive", "whitted_spheres_96x54_b0",
+           "whitted_mesh_96x54_b5"]
+
+
+@pytest.mark.parametrize("name", WHITTED)
+def test_whitted_images(name):
+    """RT_MODE_WHITTED against the project-12 snapshot of the reference (its Whitted-style shader with the
+    photon maps switched off): direct light with adaptive soft shadows (b0), and the full recursion with
+    Monte-Carlo indirect light, glossy reflection and refraction (b5) - bit for bit."""
+    g = O.load_golden(name)
+    s = O.scene_from_golden(g)
+    seed, mn, mx, w, h, bounces = [int(x) for x in g["params"]]
+    prm = abi.default_params(seed=seed, min_spp=mn, max_spp=mx, delta_max=float(g["delta"]), max_bounces=bounces,
+                             mode=abi.RT_MODE_WHITTED)
+    fr = O.render(s, prm, w, h)
+    assert np.array_equal(fr.object_id, g["object_id"]), "primary-hit ids"
+    assert_bits_equal(fr.z, g["z"], "z-buffer")
+    assert np.array_equal(fr.sample_count, g["sample_count"]), "sample counts"
+    assert_bits_equal(fr.linear, g["linear"], "linear radiance")
+    assert np.array_equal(fr.rgb, g["rgb"]), "8-bit image"
+    if "adaptive" in name:
+        assert len(np.unique(g["sample_count"])) > 3
+    if name.endswith("b5"):
+        # the recursion changes the picture: mirrors / glass are not black any more
+        b0 = abi.default_params(seed=seed, min_spp=mn, max_spp=mx, delta_max=float(g["delta"]), max_bounces=0,
+                                mode=abi.RT_MODE_WHITTED)
+        assert np.abs(O.render(s, b0, w, h).linear - fr.linear).max() > 0.05
