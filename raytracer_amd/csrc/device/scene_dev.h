@@ -49,6 +49,7 @@ struct DScene {
     int32_t n_nodes;
     int32_t n_lights;
     float background[3];
+    float environment[3]; // what a secondary ray of the Whitted-style shader sees when it leaves the scene
     int32_t stack_levels; // BVH stack entries a lane may need (deepest mesh + 2), 0 without meshes
     int32_t lds_levels;   // of which in LDS; the rest in stack_overflow
     uint2 *stack_overflow; // [(stack_levels - lds_levels)][threads of the largest grid]

@@ -1,6 +1,7 @@
 // C ABI of the GPU backend: context, scene upload, frame rendering, batch queries.
 // Host-side control only; the arithmetic lives in device/*.h.
 #include "device/pathsm.h"
+#include "device/whitted.h"
 #include "rt_mi355x.h"
 
 #include <algorithm>
@@ -139,9 +140,11 @@ float halton(int index, int base) // src/rng.h:103-112
 int validate_params(rt_ctx *ctx, const rt_render_params *p)
 {
     if (!p) return ctx->fail(RT_ERR_INVALID, "null render params");
-    if (p->mode != RT_MODE_PATH) return ctx->fail(RT_ERR_UNSUPPORTED, "unknown render mode %d", p->mode);
+    if (p->mode != RT_MODE_PATH && p->mode != RT_MODE_WHITTED) return ctx->fail(RT_ERR_UNSUPPORTED, "unknown render mode %d", p->mode);
     if (p->min_spp < 1 || p->max_spp < p->min_spp) return ctx->fail(RT_ERR_INVALID, "need 1 <= min_spp <= max_spp");
     if (p->max_bounces < 0 || p->max_bounces > 65535) return ctx->fail(RT_ERR_INVALID, "max_bounces must be 0..65535");
+    if (p->mode == RT_MODE_WHITTED && p->max_bounces > kMaxWhittedBounces)
+        return ctx->fail(RT_ERR_INVALID, "the Whitted-style shader takes max_bounces 0..%d (its ray tree grows as 3^bounces)", kMaxWhittedBounces);
     if (p->halton_period < 1 || p->halton_period > 64) return ctx->fail(RT_ERR_INVALID, "halton_period must be 1..64");
     if (p->tile_size < 1) return ctx->fail(RT_ERR_INVALID, "tile_size < 1");
     if (p->tile_world < 1 || p->tile_rank < 0 || p->tile_rank >= p->tile_world)
@@ -167,6 +170,13 @@ const void *paths_kernel(bool counting, int ray_levels, bool lockstep)
     if (ray_levels <= 1) return counting ? (const void *)k_paths<true, 1> : (const void *)k_paths<false, 1>;
     if (ray_levels == 2) return counting ? (const void *)k_paths<true, 2> : (const void *)k_paths<false, 2>;
     return counting ? (const void *)k_paths<true, 5> : (const void *)k_paths<false, 5>;
+}
+
+const void *whitted_kernel(bool counting, int ray_levels)
+{
+    if (ray_levels <= 1) return counting ? (const void *)k_whitted<true, 1> : (const void *)k_whitted<false, 1>;
+    if (ray_levels == 2) return counting ? (const void *)k_whitted<true, 2> : (const void *)k_whitted<false, 2>;
+    return counting ? (const void *)k_whitted<true, 5> : (const void *)k_whitted<false, 5>;
 }
 
 const void *rays_kernel(bool counting, int ray_levels)
@@ -333,6 +343,8 @@ int rt_init(int device, rt_ctx **out)
                           (const void *)k_paths<true, 1>, (const void *)k_paths<true, 2>, (const void *)k_paths<true, 5>,
                           (const void *)k_rays<false, 1, PoolIO>, (const void *)k_rays<false, 2, PoolIO>, (const void *)k_rays<false, 5, PoolIO>,
                           (const void *)k_rays<true, 1, PoolIO>, (const void *)k_rays<true, 2, PoolIO>, (const void *)k_rays<true, 5, PoolIO>,
+                          (const void *)k_whitted<false, 1>, (const void *)k_whitted<false, 2>, (const void *)k_whitted<false, 5>,
+                          (const void *)k_whitted<true, 1>, (const void *)k_whitted<true, 2>, (const void *)k_whitted<true, 5>,
                           (const void *)k_trace, (const void *)k_trace_shadow, (const void *)k_trace_paths})
         (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipDeviceProp_t prop;
@@ -513,6 +525,7 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc)
     S.lights = ctx->d_lights.as<rt_light>();
     S.n_nodes = (int)nn; S.n_lights = (int)sc->n_lights;
     memcpy(S.background, sc->background, 12);
+    memcpy(S.environment, sc->environment, 12);
     ctx->mesh_bufs.swap(bufs);
     ctx->scene = S;
     ctx->ray_levels = ray_levels;
@@ -611,7 +624,23 @@ int rt_render(rt_ctx *ctx, const rt_render_params *prm, rt_frame_out *out)
             const uint64_t items = (uint64_t)cnt * nk;
             const int32_t *act = ctx->d_active[cur].as<int32_t>() + first;
             HIP_TRY(ctx, hipEventRecord(ctx->evk0, s));
-            if (ctx->use_wavefront) {
+            if (prm->mode == RT_MODE_WHITTED) {
+                const void *fn = whitted_kernel(ctx->counting, ctx->ray_levels);
+                int per_cu = 1;
+                HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kBlock, lds));
+                per_cu = std::max(1, std::min(per_cu, 8));
+                const dim3 grid((unsigned)std::min<uint64_t>((items + kBlock - 1) / kBlock, (uint64_t)ctx->n_cu * per_cu));
+                HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue.p, 0, kQueueBytes, s));
+                DScene a_scene = ctx->scene;
+                const float *a_hal = ctx->d_halton.as<float>();
+                uint64_t a_items = items;
+                int a_k0 = k0, a_nk = nk;
+                float4 *a_sbuf = ctx->d_sbuf.as<float4>();
+                DCounters *a_ctr = ctx->d_counters.as<DCounters>();
+                unsigned long long *a_queue = ctx->d_queue.as<unsigned long long>();
+                void *args[] = {&a_scene, &F, &a_hal, &act, &a_items, &a_k0, &a_nk, &a_sbuf, &P, &a_ctr, &a_queue};
+                HIP_TRY(ctx, hipLaunchKernel(fn, grid, dim3(kBlock), args, lds, s));
+            } else if (ctx->use_wavefront) {
                 if (int rc = render_wavefront(ctx, F, act, items, k0, nk, P, lds)) return rc;
             } else {
             // persistent launch: as many workgroups as the chip holds at once (more would only queue up)

@@ -157,6 +157,58 @@ def test_mesh_scene_vs_oracle_with_counters(ctx):
     assert abs(int(c.tri_tests) - int(cpu.stats.tri_tests)) <= 5e-3 * cpu.stats.tri_tests
 
 
+WHITTED = ["whitted_a_96x54_b0", "whitted_a_96x54_b5", "whitted_a_64x36_adaptive", "whitted_spheres_96x54_b0",
+           "whitted_mesh_96x54_b5"]
+
+
+@pytest.mark.parametrize("name", WHITTED)
+def test_whitted_images_vs_reference(ctx, name):
+    """RT_MODE_WHITTED (k_whitted) against images of the reference's project-12 snapshot: primary-hit ids and
+    z bit-exact; the shaded image within the PSNR bar (cosf/sinf feed the shadow-fan and lobe directions, powf
+    the highlights, so single samples can flip at shadow edges)."""
+    g = O.load_golden(name)
+    s = O.scene_from_golden(g)
+    seed, mn, mx, w, h, bounces = [int(x) for x in g["params"]]
+    prm = abi.default_params(seed=seed, min_spp=mn, max_spp=mx, delta_max=float(g["delta"]), max_bounces=bounces,
+                             mode=abi.RT_MODE_WHITTED)
+    fr = render_gpu(ctx, s, prm, w, h)
+    assert np.array_equal(fr.object_id, g["object_id"]), "primary-hit ids"
+    assert np.array_equal(bits(fr.z), bits(g["z"])), "z-buffer"
+    same_n = (fr.sample_count == g["sample_count"]).mean()
+    assert same_n >= (1.0 if mn == mx else 0.97), f"sample counts agree on {same_n:.4f}"
+    p = O.psnr(fr.rgb, g["rgb"])
+    assert p >= PSNR_MIN, f"PSNR {p:.2f} dB vs the reference image"
+    # most pixels agree to float rounding in linear radiance
+    close = np.all(np.abs(fr.linear - g["linear"]) <= 1e-4 * np.maximum(1.0, np.abs(g["linear"])), axis=-1)
+    assert close.mean() >= 0.97, f"only {close.mean():.4f} of the pixels agree in linear radiance"
+
+
+@pytest.mark.parametrize("bounces,w,h,spp", [(0, 240, 135, 4), (3, 160, 90, 2)])
+def test_whitted_spheres_vs_oracle(ctx, bounces, w, h, spp):
+    """The sphere/plane configuration (67 nodes) through the Whitted-style shader against the oracle, with ray counts."""
+    from raytracer_amd import scenes
+    hs = lib.HostScene.from_string(scenes.spheres_scene_xml(width=w, height=h))
+    prm = abi.default_params(seed=7, min_spp=spp, max_spp=spp, max_bounces=bounces, mode=abi.RT_MODE_WHITTED)
+    gpu = render_gpu(ctx, hs, prm, w, h)
+    cpu = O.render(hs, prm, w, h)
+    assert np.array_equal(gpu.object_id, cpu.object_id)
+    assert np.array_equal(bits(gpu.z), bits(cpu.z))
+    assert O.psnr(gpu.rgb, cpu.rgb) >= PSNR_MIN
+    c = ctx.counters()
+    assert c.camera_paths == w * h * spp
+    assert abs(int(c.closest_rays) - int(cpu.stats.closest)) <= 5e-3 * cpu.stats.closest
+    assert abs(int(c.shadow_rays) - int(cpu.stats.shadow)) <= 5e-3 * cpu.stats.shadow
+
+
+def test_whitted_rejects_deep_recursion(ctx):
+    s = O.scene_from_golden(O.load_golden("scene_a"))
+    ctx.upload(s.desc)
+    ctx.set_camera(s.camera, 8, 8)
+    with pytest.raises(lib.RtError) as e:
+        ctx.render(abi.default_params(mode=abi.RT_MODE_WHITTED, max_bounces=9, min_spp=1, max_spp=1))
+    assert e.value.code == abi.RT_ERR_INVALID
+
+
 def test_pipelines_agree(monkeypatch):
     """The lock-step path kernel (default), the wavefront pipeline (logic kernel + ray-list kernel) and
     the fused path kernel (ray-level regeneration in one launch) run the same per-path arithmetic:
