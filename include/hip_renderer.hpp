@@ -131,6 +131,7 @@ public:
         params.min_spp = 128; params.max_spp = 128; params.delta_max = 0.01f;
         params.max_bounces = 50; params.bias = 0.002f; params.halton_period = 16;
         params.tile_size = 16; params.tile_rank = 0; params.tile_world = 1; params.seed = 7;
+        params.photon_flags = 0; params.gather_radius = 3.0f;
         if (rt_init(device, &ctx) != RT_OK) { Fail("rt_init", rt_last_error(nullptr)); ctx = nullptr; }
     }
     ~HipRenderer()

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 1
+#define RT_ABI_VERSION 2
 
 typedef struct rt_ctx rt_ctx;
 
@@ -137,6 +137,16 @@ typedef struct rt_camera {
  *                  one Monte-Carlo indirect ray on the first two bounces, glossy reflection and refraction. */
 typedef enum rt_mode { RT_MODE_PATH = 0, RT_MODE_WHITTED = 1 } rt_mode;
 
+/* The four photon-map switches of the snapshot (project12.zip src/renderer.cpp:4-7), as bits.
+ * They select how the photon maps are filled (src/main.cpp:292-470 there) and what the Whitted-style
+ * shader takes from them (src/materials.cpp:24-72,75 there). */
+enum {
+    RT_PM_DIRECT = 1,      /* doingDirectWithPhotonMapping: direct light from the global map, no light loop   */
+    RT_PM_INDIRECT = 2,    /* doingIndirectWithPhotonMapping: indirect light from the global map, no Monte-Carlo ray */
+    RT_PM_CAUSTICS = 4,    /* doingCaustics: caustics map                                                     */
+    RT_PM_MONTE_CARLO = 8  /* monteCarloWithPhoton: global map holds first hits only                          */
+};
+
 /* Everything the reference fixes at compile time (src/main.cpp:93,107,164,
  * 220-221,262,273-274,369) plus the seeding convention and the tile shard. */
 typedef struct rt_render_params {
@@ -153,6 +163,10 @@ typedef struct rt_render_params {
     uint64_t seed;         /* frame seed; pixel p uses seed + p*0x9E3779B97F4A7C15,
                               PCG stream 0 for the four per-pixel offsets and
                               stream k+1 for sample k */
+    int32_t photon_flags;  /* RT_MODE_WHITTED: RT_PM_* bits; 0 = no photon maps. The maps must have been built
+                              (rt_photons_fill or rt_photons_build) with the same bits. */
+    float gather_radius;   /* RT_MODE_WHITTED with photon maps: search radius of the 128-photon irradiance
+                              estimate; reference: 3.0 */
 } rt_render_params;
 
 /* Output planes, row-major, row 0 = top (reference: RenderImage, src/renderer.h:38-106).
@@ -183,6 +197,8 @@ typedef struct rt_counters {
     uint64_t camera_paths;
     uint64_t box_tests;     /* BVH slab tests     */
     uint64_t tri_tests;     /* triangle tests     */
+    uint64_t gathers;       /* irradiance estimates (photon-map lookups) */
+    uint64_t photon_visits; /* kd-tree nodes visited by them (counting variant only) */
     double kernel_ms;       /* GPU time of the last rt_render, HIP events on the render stream */
     double trace_kernel_ms; /* of which: the path-tracing kernel(s) */
     uint32_t trace_launches;
@@ -224,6 +240,55 @@ typedef struct rt_hit_brief {
     float u, v;
 } rt_hit_brief;
 int rt_trace_brief(rt_ctx *ctx, const float *rays6, const float *t_max, int n, rt_hit_brief *out);
+
+/* ---- photon maps: replaces class PhotonMap (src/photonmap.h:38-414) and the emission loops of the
+ * project-12 snapshot's main() (project12.zip src/main.cpp:262-470) ---- */
+
+/* One photon, bit-compatible with PhotonMap::PhotonData (src/photonmap.h:42-59): 32 bytes. */
+typedef struct rt_photon {
+    float pos[3];
+    float power;    /* largest colour channel (scaled by 1/stored once the map is built) */
+    float dir[3];   /* direction of travel */
+    uint8_t rgb[3]; /* colour / power, 8 bits per channel (Color24) */
+    uint8_t plane;  /* kd-tree split axis 0..2 of a node that has children */
+} rt_photon;
+
+enum { RT_MAP_GLOBAL = 0, RT_MAP_CAUSTICS = 1 };
+#define RT_GATHER_MAX_PHOTONS 128 /* EstimateIrradiance<128> (project12.zip src/materials.cpp:54,65) */
+
+typedef struct rt_photon_params {
+    int32_t flags;        /* RT_PM_* bits */
+    uint32_t n_global;    /* capacity of the global map   (photonMap.Resize(n));   reference: 100000 */
+    uint32_t n_caustic;   /* capacity of the caustics map (causticsMap.Resize(n)); reference: 100000 */
+    int32_t max_segments; /* bound on the TraceRay calls of one photon path; the reference has none
+                             (a path ends by absorption), 64 loses less than 1e-6 of the photons of its scene */
+    uint64_t seed;        /* path p of the global map draws from PCG stream p of seed ^ 0x50484F54,
+                             path p of the caustics map from stream p of seed ^ 0x43415553 */
+} rt_photon_params;
+
+/* Trace photon paths [path_begin, path_begin + path_count) of one map and return the photons they
+ * store, in path order (within a path in the order stored) - the order in which the reference's
+ * serial loop would have added them.  At most `capacity` photons are written (the first ones in that
+ * order); *n_stored receives the number the paths stored in total, which may exceed capacity.
+ * Powers are unscaled.  `out` is host memory, or device memory if device_memory != 0. */
+int rt_photons_emit(rt_ctx *ctx, const rt_photon_params *params, int which, uint64_t path_begin, uint64_t path_count,
+                    rt_photon *out, uint32_t capacity, uint64_t *n_stored, int device_memory);
+
+/* Make `photons[0..n)` (emission order, unscaled) the context's map `which`: powers are scaled by 1/n
+ * (ScalePhotonPowers, src/photonmap.h:82), the left-balanced kd-tree is built exactly as
+ * PrepareForIrradianceEstimation / BalanceSegment do (src/photonmap.h:176-264) and uploaded. n = 0 clears the map. */
+int rt_photons_build(rt_ctx *ctx, int which, const rt_photon *photons, uint32_t n, int device_memory);
+
+/* One GPU: emit rounds of paths until each map selected by params->flags holds its capacity, then build. */
+int rt_photons_fill(rt_ctx *ctx, const rt_photon_params *params);
+
+/* The balanced map as PhotonMap::GetPhotons() exposes it (heap order, node i at index i-1). dst may be null to query *n. */
+int rt_photons_download(rt_ctx *ctx, int which, rt_photon *dst, uint32_t *n);
+
+/* EstimateIrradiance<128>(irrad, dir, radius, pos, normal, 1) (src/photonmap.h:268-414) for n points.
+ * pos3 / normal3 / irradiance3 are host arrays of 3 floats per point. */
+int rt_photons_irradiance(rt_ctx *ctx, int which, const float *pos3, const float *normal3, int n, float radius,
+                          float *irradiance3);
 
 int rt_get_counters(rt_ctx *ctx, rt_counters *out);
 /* box_tests / tri_tests are only counted while counting is on (a separately

@@ -9,6 +9,7 @@ reference source text.
 
     python oracle/make_golden.py            # regenerate everything
     python oracle/make_golden.py --whitted  # only the project-12 (Whitted-style shader) fixtures
+    python oracle/make_golden.py --photons  # only the photon-map fixtures
 """
 import os
 import subprocess
@@ -82,10 +83,36 @@ def whitted():
         image("whitted_mesh_96x54_b5", p, scene_bundle(p, cwd=tmp, harness=H), 7, 4, 4, 0.01, 96, 54, 5, cwd=tmp)
 
 
+def photons():
+    """Photon maps of the project-12 snapshot: emission, balanced kd-tree, irradiance estimates, and images of
+    its Whitted-style shader reading the maps.  flags = RT_PM_* bits the harness was compiled with."""
+    HPM = os.path.join(HERE, "_ref", "ref_harness_p12pm")  # indirect light + caustics from photon maps (as shipped)
+    HPD = os.path.join(HERE, "_ref", "ref_harness_p12pd")  # direct light from the photon map
+    for h in (HPM, HPD):
+        if not os.path.exists(h):
+            sys.exit("build the snapshot harnesses first: make -C oracle ref12")
+    sa = scene_bundle(REF_SCENE, harness=HPM)
+    # params = seed, n_global, n_caustic, max_segments, flags
+    r = run(REF_SCENE, "photons", 7, 4000, 1500, 64, 384, 3, harness=HPM)
+    save("photons_a_indirect_caustics", **sa, params=np.array([7, 4000, 1500, 64, 2 | 4], np.int64), radius=np.float32(3), **r)
+    r = run(REF_SCENE, "photons", 11, 3000, 0, 64, 256, 3, harness=HPD)
+    save("photons_a_direct", **sa, params=np.array([11, 3000, 0, 64, 1], np.int64), radius=np.float32(3), **r)
+    save("kat_photon_a", **sa, seed=np.int64(5), **run(REF_SCENE, "kat_photon", 512, 5, harness=HPM))
+    # images; params = seed, min spp, max spp, width, height, max_bounces, n_global, n_caustic, max_segments, flags
+    for name, H, flags, args in (("whitted_pm_a_64x36_b5", HPM, 2 | 4, (7, 4, 4, 0.01, 64, 36, 5, 4000, 1500, 64)),
+                                 ("whitted_pm_a_64x36_b0", HPM, 2 | 4, (5, 2, 2, 0.01, 64, 36, 0, 2500, 800, 64)),
+                                 ("whitted_pd_a_64x36_b5", HPD, 1, (9, 2, 2, 0.01, 64, 36, 5, 3000, 0, 64))):
+        img = run(REF_SCENE, "render_whitted", *args, harness=H)
+        seed, mn, mx, delta, w, h, bounces, ng, nc, seg = args
+        save(name, **sa, params=np.array([seed, mn, mx, w, h, bounces, ng, nc, seg, flags], np.int64), delta=np.float32(delta), **img)
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     if "--whitted" in sys.argv:  # only the snapshot's fixtures
         return whitted()
+    if "--photons" in sys.argv:
+        return photons()
     if not os.path.exists(HARNESS):
         sys.exit("build the harness first: make -C oracle ref")
 
@@ -135,6 +162,7 @@ def main():
         img = run(p, "render", 7, 8, 8, 0.01, 96, 54, cwd=tmp)
         save("image_mesh_96x54_s8", **small, params=np.array([7, 8, 8, 96, 54], np.int64), delta=np.float32(0.01), **img)
     whitted()
+    photons()
 
 
 if __name__ == "__main__":

@@ -238,12 +238,250 @@ static inline uint64_t pixelSeed(uint64_t frameSeed, uint64_t pixelIndex)
 }
 
 #ifdef REF_P12
-// The snapshot's switches (its renderer.cpp, which the harness replaces): no photon maps.
+// The snapshot's switches (its renderer.cpp, which the harness replaces).  They are compile-time
+// constants there too; `make ref12` builds one harness with all four off and one per photon-map
+// combination that has goldens (-DPM_DIRECT=1 ... on the compiler line).
+#ifndef PM_DIRECT
+#define PM_DIRECT 0
+#endif
+#ifndef PM_INDIRECT
+#define PM_INDIRECT 0
+#endif
+#ifndef PM_CAUSTICS
+#define PM_CAUSTICS 0
+#endif
+#ifndef PM_MONTE_CARLO
+#define PM_MONTE_CARLO 0
+#endif
 Renderer renderer;
-const bool doingDirectWithPhotonMapping{ false };
-const bool doingIndirectWithPhotonMapping{ false };
-const bool doingCaustics{ false };
-const bool monteCarloWithPhoton{ false };
+const bool doingDirectWithPhotonMapping{ PM_DIRECT != 0 };
+const bool doingIndirectWithPhotonMapping{ PM_INDIRECT != 0 };
+const bool doingCaustics{ PM_CAUSTICS != 0 };
+const bool monteCarloWithPhoton{ PM_MONTE_CARLO != 0 };
+
+// ---- photon maps: the snapshot's emission loops (its main.cpp:292-470) with one PCG stream per photon
+// path instead of the one global stream: path p of the global map starts from SetSequence(p, seed ^ "PHOT"),
+// path p of the caustics map from SetSequence(p, seed ^ "CAUS").  Paths run in order until the map is
+// full, exactly as there; `maxSegments` bounds the TraceRay calls of one path (the snapshot has no bound).
+static PhotonMap g_photonMap, g_causticsMap;
+static std::vector<PhotonMap::PhotonData> g_rawGlobal, g_rawCaustic;
+static uint64_t g_pathsGlobal = 0, g_pathsCaustic = 0;
+static const uint64_t kSeedGlobal = 0x50484F54ULL, kSeedCaustic = 0x43415553ULL;
+
+static void fillPhotonMaps(uint64_t seed, int nGlobal, int nCaustic, int maxSegments)
+{
+    RNG &rng = tileThreads::rng;
+    g_photonMap.Resize(nGlobal);
+    g_causticsMap.Resize(nCaustic);
+    renderer.SetPhotonMap(&g_photonMap);
+    renderer.SetCausticsMap(&g_causticsMap);
+    const Light *light{ renderer.GetScene().lights[0] };
+    g_pathsGlobal = g_pathsCaustic = 0;
+    const bool directOnly = doingDirectWithPhotonMapping || monteCarloWithPhoton; // the first branch's condition
+    bool mapIsFull = nGlobal <= 0;
+    if (directOnly) {
+        for (uint64_t p = 0; !mapIsFull; ++p) {
+            rng.SetSequence(p, seed ^ kSeedGlobal);
+            g_pathsGlobal = p + 1;
+            Ray photonRay;
+            Color c;
+            light->RandomPhoton(rng, photonRay, c);
+            photonRay.p += photonRay.dir * 0.0002f;
+            HitInfo hInfo{};
+            if (!renderer.TraceRay(photonRay, hInfo)) continue;
+            if (hInfo.light) continue; // the snapshot would dereference a null node here; cannot happen with one light
+            const Material *material{ hInfo.node->GetMaterial() };
+            if (!material->IsPhotonSurface()) continue;
+            if (!g_photonMap.AddPhoton(hInfo.p, photonRay.dir, c)) mapIsFull = true;
+        }
+    } else if (doingIndirectWithPhotonMapping) {
+        for (uint64_t p = 0; !mapIsFull; ++p) {
+            rng.SetSequence(p, seed ^ kSeedGlobal);
+            g_pathsGlobal = p + 1;
+            Ray photonRay;
+            Color c;
+            light->RandomPhoton(rng, photonRay, c);
+            bool firstHit{ true };
+            for (int seg = 0; seg < maxSegments; ++seg) {
+                photonRay.p += photonRay.dir * 0.0002f;
+                HitInfo hInfo{};
+                if (!renderer.TraceRay(photonRay, hInfo) || hInfo.light) break;
+                SamplerInfo sInfo{ rng };
+                sInfo.SetHit(photonRay, hInfo);
+                DirSampler::Info info{};
+                Vec3f newDir{};
+                const Material *material{ hInfo.node->GetMaterial() };
+                const bool bounce{ material->GenerateSample(sInfo, newDir, info) };
+                if (firstHit) {
+                    if (!bounce || (doingCaustics && info.lobe != DirSampler::Lobe::DIFFUSE)) break;
+                    firstHit = false;
+                    photonRay.dir = newDir;
+                    photonRay.p = hInfo.p;
+                    c *= info.mult / info.prob;
+                    continue;
+                }
+                if (material->IsPhotonSurface() && !g_photonMap.AddPhoton(hInfo.p, photonRay.dir, c)) { mapIsFull = true; break; }
+                if (!bounce) break;
+                photonRay.dir = newDir;
+                photonRay.p = hInfo.p;
+                c *= info.mult / info.prob;
+            }
+        }
+    }
+    g_rawGlobal.assign(g_photonMap.photons.begin() + 1, g_photonMap.photons.begin() + 1 + g_photonMap.NumPhotons());
+    g_photonMap.ScalePhotonPowers(1.0f / static_cast<float>(g_photonMap.NumPhotons()));
+    g_photonMap.PrepareForIrradianceEstimation();
+
+    g_rawCaustic.clear();
+    if (doingCaustics) {
+        mapIsFull = nCaustic <= 0;
+        for (uint64_t p = 0; !mapIsFull; ++p) {
+            rng.SetSequence(p, seed ^ kSeedCaustic);
+            g_pathsCaustic = p + 1;
+            Ray photonRay;
+            Color c;
+            light->RandomPhoton(rng, photonRay, c);
+            bool firstHit{ true };
+            for (int seg = 0; seg < maxSegments; ++seg) {
+                photonRay.p += photonRay.dir * 0.0002f;
+                HitInfo hInfo{};
+                if (!renderer.TraceRay(photonRay, hInfo) || hInfo.light) break;
+                SamplerInfo sInfo{ rng };
+                sInfo.SetHit(photonRay, hInfo);
+                DirSampler::Info info{};
+                Vec3f newDir{};
+                const Material *material{ hInfo.node->GetMaterial() };
+                const bool bounce{ material->GenerateSample(sInfo, newDir, info) };
+                if (firstHit) {
+                    if (!bounce || info.lobe == DirSampler::Lobe::DIFFUSE) break;
+                    firstHit = false;
+                    photonRay.dir = newDir;
+                    photonRay.p = hInfo.p;
+                    c *= info.mult / info.prob;
+                    continue;
+                }
+                if (material->IsPhotonSurface()) { mapIsFull = !g_causticsMap.AddPhoton(hInfo.p, photonRay.dir, c); break; }
+                if (!bounce) break;
+                photonRay.dir = newDir;
+                photonRay.p = hInfo.p;
+                c *= info.mult / info.prob;
+            }
+        }
+        g_rawCaustic.assign(g_causticsMap.photons.begin() + 1, g_causticsMap.photons.begin() + 1 + g_causticsMap.NumPhotons());
+        g_causticsMap.ScalePhotonPowers(1.0f / static_cast<float>(g_causticsMap.NumPhotons()));
+        g_causticsMap.PrepareForIrradianceEstimation();
+    }
+}
+
+// 32-byte photon records as 8 words each.  AddPhoton leaves the last byte (split plane) indeterminate
+// and only nodes with a child get it set, so it is written out as plane for those and 0 otherwise.
+static void dumpPhotons(const char *name, const PhotonMap::PhotonData *p, size_t n, bool balanced)
+{
+    static_assert(sizeof(PhotonMap::PhotonData) == 32, "photon record");
+    std::vector<uint32_t> w(n * 8);
+    if (n) memcpy(w.data(), p, n * 32);
+    for (size_t i = 0; i < n; ++i) {
+        uint8_t *b = (uint8_t *)&w[i * 8 + 7];
+        const bool hasChild = balanced && 2 * (i + 1) <= n; // 1-based index i+1
+        b[3] = hasChild ? (uint8_t)(b[3] & 3) : 0;
+    }
+    dumpU(name, w, {n, 8});
+}
+
+static void dumpPhotonMaps()
+{
+    dumpPhotons("pm_global_raw", g_rawGlobal.data(), g_rawGlobal.size(), false);
+    dumpPhotons("pm_caustic_raw", g_rawCaustic.data(), g_rawCaustic.size(), false);
+    dumpPhotons("pm_global_tree", g_photonMap.GetPhotons(), (size_t)g_photonMap.NumPhotons(), true);
+    dumpPhotons("pm_caustic_tree", g_rawCaustic.empty() ? nullptr : g_causticsMap.GetPhotons(), g_rawCaustic.size(), true);
+    std::vector<int32_t> paths = { (int32_t)g_pathsGlobal, (int32_t)g_pathsCaustic };
+    dumpI("pm_paths", paths, {2});
+}
+
+// RandomPhoton for paths 0..n-1 and the snapshot's GenerateSample for every material at synthetic surface points
+static void cmdKatPhoton(int n, uint64_t seed)
+{
+    const Scene &sc = renderer.GetScene();
+    const Light *light = sc.lights[0];
+    RNG &rng = tileThreads::rng;
+    std::vector<float> em((size_t)n * 9);
+    for (int i = 0; i < n; ++i) {
+        rng.SetSequence((uint64_t)i, seed ^ kSeedGlobal);
+        Ray r; Color c;
+        light->RandomPhoton(rng, r, c);
+        float *o = &em[(size_t)i * 9];
+        o[0] = r.p.x; o[1] = r.p.y; o[2] = r.p.z; o[3] = r.dir.x; o[4] = r.dir.y; o[5] = r.dir.z; o[6] = c.r; o[7] = c.g; o[8] = c.b;
+    }
+    dumpF("ph_emit", em, {(size_t)n, 9});
+    size_t nm = sc.materials.size();
+    RNG g(98, seed);
+    std::vector<float> in((size_t)n * 9), mg((size_t)n * nm * 7);
+    std::vector<int32_t> mflags((size_t)n * nm * 3), frontv(n);
+    for (int i = 0; i < n; ++i) {
+        HitInfo h{};
+        h.p = Vec3f{ (g.RandomFloat() - 0.5f) * 28.0f, (g.RandomFloat() - 0.5f) * 36.0f, g.RandomFloat() * 23.0f };
+        h.N = Vec3f{ g.RandomFloat() - 0.5f, g.RandomFloat() - 0.5f, g.RandomFloat() - 0.5f };
+        h.GN = h.N;
+        h.z = 1.0f + g.RandomFloat() * 30.0f;
+        h.front = g.RandomFloat() < 0.7f;
+        Ray r;
+        r.dir = Vec3f{ g.RandomFloat() - 0.5f, g.RandomFloat() - 0.5f, g.RandomFloat() - 0.5f } * 3.0f;
+        if ((r.dir % h.N) > 0.0f && (i % 5) != 0) r.dir = -r.dir;
+        r.p = h.p - r.dir * h.z;
+        float *I = &in[(size_t)i * 9];
+        memcpy(I, &h.p.x, 12); memcpy(I + 3, &h.N.x, 12); memcpy(I + 6, &r.dir.x, 12);
+        frontv[i] = h.front;
+        SamplerInfo sI{ rng };
+        sI.SetHit(r, h);
+        for (size_t m = 0; m < nm; ++m) {
+            rng.SetSequence((uint64_t)i + 1, seed ^ (0x2000 + m));
+            DirSampler::Info si{};
+            Vec3f bd{ 0, 0, 0 };
+            bool b = sc.materials[m]->GenerateSample(sI, bd, si);
+            float *q = &mg[((size_t)i * nm + m) * 7];
+            q[0] = bd.x; q[1] = bd.y; q[2] = bd.z; q[3] = si.mult.r; q[4] = si.mult.g; q[5] = si.mult.b; q[6] = si.prob;
+            int32_t *f = &mflags[((size_t)i * nm + m) * 3];
+            f[0] = b; f[1] = (int)si.lobe; f[2] = (int)rng.RandomInt(); // the next draw pins the number of draws consumed
+        }
+    }
+    dumpF("ph_smp_in", in, {(size_t)n, 9}); dumpI("ph_smp_front", frontv, {(size_t)n});
+    dumpF("ph_smp_gen", mg, {(size_t)n, nm, 7}); dumpI("ph_smp_flags", mflags, {(size_t)n, nm, 3});
+}
+
+// photons seed nGlobal nCaustic maxSegments nQueries radius: the two maps, then EstimateIrradiance<128> at the
+// primary hits of a coarse grid of camera rays and at random points with random normals
+static void cmdPhotons(uint64_t seed, int nGlobal, int nCaustic, int maxSegments, int nQ, float radius)
+{
+    fillPhotonMaps(seed, nGlobal, nCaustic, maxSegments);
+    dumpPhotonMaps();
+    const Camera &cam = renderer.GetCamera();
+    std::vector<float> q, out;
+    RNG g(31, seed);
+    int side = 1;
+    while (side * side < nQ / 2) ++side;
+    for (int k = 0; k < nQ; ++k) {
+        Vec3f P, N;
+        if (k < side * side) {
+            const float sx = -tileThreads::imagePlaneHalfWidth + 2 * tileThreads::imagePlaneHalfWidth * ((k % side) + 0.5f) / side;
+            const float sy = tileThreads::imagePlaneHalfHeight - 2 * tileThreads::imagePlaneHalfHeight * ((k / side) + 0.5f) / side;
+            const Ray ray{ cam.pos, tileThreads::cameraToWorld * Vec3f{ sx, sy, -cam.focaldist } };
+            HitInfo h{};
+            if (!renderer.TraceRay(ray, h) || h.light) continue;
+            P = h.p; N = h.N.GetNormalized();
+        } else {
+            P = Vec3f{ (g.RandomFloat() - 0.5f) * 30.0f, (g.RandomFloat() - 0.5f) * 40.0f, g.RandomFloat() * 24.0f };
+            N = Vec3f{ g.RandomFloat() - 0.5f, g.RandomFloat() - 0.5f, g.RandomFloat() - 0.5f }.GetNormalized();
+        }
+        Color ig{ 0.0f }, ic{ 0.0f };
+        Vec3f dg{ 0, 0, 0 }, dc{ 0, 0, 0 };
+        if (g_photonMap.NumPhotons() > 0) g_photonMap.EstimateIrradiance<128>(ig, dg, radius, P, N, 1.0f);
+        if (g_causticsMap.NumPhotons() > 0) g_causticsMap.EstimateIrradiance<128>(ic, dc, radius, P, N, 1.0f);
+        q.insert(q.end(), { P.x, P.y, P.z, N.x, N.y, N.z });
+        out.insert(out.end(), { ig.r, ig.g, ig.b, ic.r, ic.g, ic.b });
+    }
+    dumpF("pm_query", q, {q.size() / 6, 6});
+    dumpF("pm_irradiance", out, {out.size() / 6, 6});
+}
 
 // CanBounce with a run-time limit.  The snapshot copies the ShadeInfo by value into a plain
 // ShadeInfo for every secondary ray, so below the camera ray its compiled-in limit of 5 is
@@ -255,8 +493,13 @@ struct HarnessShadeInfo : public ShadeInfo {
 };
 
 // the pixel loop of the snapshot (its main.cpp:160-270) with the seeding convention of cmdRender
-static void cmdRenderWhitted(uint64_t seed, int minS, int maxS, float deltaMax, int W, int H, int maxBounces)
+static void cmdRenderWhitted(uint64_t seed, int minS, int maxS, float deltaMax, int W, int H, int maxBounces,
+                             int nGlobal = 0, int nCaustic = 0, int maxSegments = 64)
 {
+    if (doingDirectWithPhotonMapping || doingIndirectWithPhotonMapping || doingCaustics || monteCarloWithPhoton) {
+        fillPhotonMaps(seed, nGlobal, nCaustic, maxSegments);
+        dumpPhotonMaps();
+    }
     g_maxBounces = maxBounces;
     setupCamera(W, H);
     flattenScene();
@@ -597,7 +840,12 @@ int main(int argc, char **argv)
 #ifdef REF_P12
     else if (cmd == "render_whitted") // seed min max delta W H max_bounces
         cmdRenderWhitted(strtoull(A(4, "7").c_str(), 0, 0), atoi(A(5, "16").c_str()), atoi(A(6, "16").c_str()), (float)atof(A(7, "0.01").c_str()),
-                         atoi(A(8, "0").c_str()), atoi(A(9, "0").c_str()), atoi(A(10, "5").c_str()));
+                         atoi(A(8, "0").c_str()), atoi(A(9, "0").c_str()), atoi(A(10, "5").c_str()),
+                         atoi(A(11, "0").c_str()), atoi(A(12, "0").c_str()), atoi(A(13, "64").c_str()));
+    else if (cmd == "kat_photon") cmdKatPhoton(atoi(A(4, "1024").c_str()), strtoull(A(5, "1").c_str(), 0, 0));
+    else if (cmd == "photons") // seed n_global n_caustic max_segments n_queries radius
+        cmdPhotons(strtoull(A(4, "7").c_str(), 0, 0), atoi(A(5, "1000").c_str()), atoi(A(6, "1000").c_str()), atoi(A(7, "64").c_str()),
+                   atoi(A(8, "256").c_str()), (float)atof(A(9, "3").c_str()));
 #else
     else if (cmd == "render")
         cmdRender(strtoull(A(4, "7").c_str(), 0, 0), atoi(A(5, "16").c_str()), atoi(A(6, "16").c_str()), (float)atof(A(7, "0.01").c_str()),

@@ -830,6 +830,384 @@ void orc_trace_path(const rt_scene_desc *sc, const float ray6[6], orc_rng *rng,
 /* ------------------------------------------------------------------------- */
 /* camera + pixel loop (src/main.cpp:271-385,399-414)                        */
 /* ------------------------------------------------------------------------- */
+static inline uint8_t to_byte(float r);
+
+/* ------------------------------------------------------------------------- */
+/* photon maps (src/photonmap.h:38-414; emission: p12 main.cpp:292-470)       */
+/* ------------------------------------------------------------------------- */
+/* PointLight::RandomPhoton (src/lights.h:92-124) */
+static void light_random_photon(const rt_light *l, orc_rng *rng, ray_t *r, v3 *c)
+{
+    float randU = orc_rng_float(rng);
+    float randV = orc_rng_float(rng);
+    const float theta = (float)(2.0f * M_PI * randU);
+    const float posZ = l->size * (1.0f - 2.0f * randV);
+    const float rProj = sqrtf(l->size * l->size - posZ * posZ);
+    /* the snapshot's lights.h and materials.h see only the C library's double cos/sin/pow/sqrt/fmod from inside
+     * their class bodies (the float overloads arrive with <math.h>, included later): products with them are
+     * formed in double and narrowed once */
+    const float posX = (float)(rProj * cos((double)theta));
+    const float posY = (float)(rProj * sin((double)theta));
+    const v3 position = vld(l->position);
+    const v3 rayPos = vadd(V3(posX, posY, posZ), position);
+    r->p = rayPos;
+    randU = orc_rng_float(rng);
+    randV = orc_rng_float(rng);
+    const float phi = (float)(2.0f * M_PI * randU);
+    const float cosTheta = randV;
+    const float sinTheta = sqrtf(1.0f - cosTheta * cosTheta);
+    const float dirX = (float)(sinTheta * cos((double)phi));
+    const float dirY = (float)(sinTheta * sin((double)phi));
+    const float dirZ = cosTheta;
+    const v3 norm = vnormalize(vsub(rayPos, position));
+    v3 u, v;
+    orthonormals(norm, &u, &v);
+    r->d = vadd(vadd(vscale(u, dirX), vscale(v, dirY)), vscale(norm, dirZ));
+    /* intensity * 8.0f * M_PI * size * size * cosTheta: Color * float each time (M_PI narrows to float) */
+    *c = vscale(vscale(vscale(vscale(vscale(vld(l->intensity), 8.0f), (float)M_PI), l->size), l->size), cosTheta);
+}
+
+/* MtlBlinn::GenerateSample of the snapshot (p12 materials.h:82-193): the photon scattering sampler.
+ * s->n is the unit shading normal, s->v the unit view vector (SamplerInfo::SetHit). */
+enum { P12_DIFFUSE = 1, P12_SPECULAR = 2, P12_TRANSMISSION = 4 };
+static int p12_mtl_generate(const rt_material *m, const orc_surface *s, orc_rng *rng, v3 *dir, v3 *mult, float *prob, int *lobe)
+{
+    float pd, ps, pt;
+    lobe_probs(m, &pd, &ps, &pt);
+    const v3 Ns = vld(s->n), V = vld(s->v);
+    const float randomNum = orc_rng_float(rng);
+    if (randomNum < pd) {
+        *lobe = P12_DIFFUSE;
+        *mult = vld(m->diffuse);
+        *prob = pd;
+        const float r1 = orc_rng_float(rng);
+        const float r2 = orc_rng_float(rng);
+        const float z = sqrtf(r1);
+        const float sinTheta = sqrtf(1.0f - r1);
+        const float phi = (float)(2.0f * M_PI * r2);
+        const float x = (float)(sinTheta * cos((double)phi));
+        const float y = (float)(sinTheta * sin((double)phi));
+        v3 u, v;
+        orthonormals(Ns, &u, &v);
+        *dir = vadd(vadd(vscale(u, x), vscale(v, y)), vscale(Ns, z));
+        return 1;
+    }
+    if (randomNum < pd + ps) {
+        *lobe = P12_SPECULAR;
+        *prob = ps;
+        const float r1 = orc_rng_float(rng);
+        const float r2 = orc_rng_float(rng);
+        const float phi = (float)(2.0f * M_PI * r1);
+        const float cosTheta = (float)pow((double)r2, (double)(1.0f / (m->glossiness + 1.0f)));
+        const float sinTheta = sqrtf(1.0f - cosTheta * cosTheta);
+        const float x = (float)(sinTheta * cos((double)phi));
+        const float y = (float)(sinTheta * sin((double)phi));
+        const float z = cosTheta;
+        v3 u, v;
+        orthonormals(Ns, &u, &v);
+        const v3 h = vadd(vadd(vscale(u, x), vscale(v, y)), vscale(Ns, z));
+        *dir = vsub(vscale(vscale(h, 2), vdot(V, h)), V);
+        *mult = vscale(vld(m->specular), vdot(*dir, Ns));
+        return vdot(*dir, Ns) > 0.0f;
+    }
+    if (randomNum < pd + ps + pt) {
+        const v3 N = s->front ? Ns : vneg(Ns);
+        *lobe = P12_TRANSMISSION;
+        *prob = pt;
+        const float r1 = orc_rng_float(rng);
+        const float r2 = orc_rng_float(rng);
+        const float phi = (float)(2.0f * M_PI * r1);
+        const float cosTheta = (float)pow((double)r2, (double)(1.0f / (m->glossiness + 1.0f)));
+        const float sinTheta = sqrtf(1.0f - cosTheta * cosTheta);
+        const float x = (float)(sinTheta * cos((double)phi));
+        const float y = (float)(sinTheta * sin((double)phi));
+        const float z = cosTheta;
+        v3 u, v;
+        orthonormals(N, &u, &v);
+        const v3 h = vadd(vadd(vscale(u, x), vscale(v, y)), vscale(N, z));
+        const float refractionRatio = s->front ? 1.0f / m->ior : m->ior;
+        const float cosTheta_i = vdot(V, h);
+        const float sinTheta_t_sq = (refractionRatio * refractionRatio) * (1.0f - cosTheta_i * cosTheta_i);
+        if (sinTheta_t_sq > 1.0f) {
+            *lobe = P12_SPECULAR;
+            *dir = vsub(vscale(vscale(h, 2), vdot(V, h)), V);
+            *mult = vscale(vld(m->refraction), fabsf(vdot(*dir, Ns)));
+            return vdot(*dir, N) > 0.0f;
+        }
+        const float cosTheta_t = sqrtf(1.0f - sinTheta_t_sq);
+        *dir = vadd(vscale(vneg(V), refractionRatio), vscale(h, refractionRatio * cosTheta_i - cosTheta_t));
+        *mult = vscale(vld(m->refraction), fabsf(vdot(*dir, Ns)));
+        return vdot(*dir, N) < 0.0f;
+    }
+    return 0;
+}
+
+void orc_light_random_photon(const rt_light *l, orc_rng *rng, float ray6[6], float c3[3])
+{
+    ray_t r; v3 c;
+    light_random_photon(l, rng, &r, &c);
+    vst(ray6, r.p); vst(ray6 + 3, r.d); vst(c3, c);
+}
+int orc_p12_mtl_generate(const rt_material *m, const orc_surface *s, orc_rng *rng, orc_sample *o)
+{
+    v3 dir = V3(0, 0, 0), mult = V3(0, 0, 0);
+    o->prob = 0.0f; o->lobe = 0; o->dist = 0.0f;
+    const int ok = p12_mtl_generate(m, s, rng, &dir, &mult, &o->prob, &o->lobe);
+    vst(o->dir, dir); vst(o->mult, mult);
+    return ok;
+}
+
+/* PhotonData::SetPower + AddPhoton (src/photonmap.h:148-172) */
+static void photon_set(rt_photon *p, v3 pos, v3 dir, v3 c)
+{
+    vst(p->pos, pos);
+    vst(p->dir, dir);
+    float power = c.x;
+    if (power < c.y) power = c.y;
+    if (power < c.z) power = c.z;
+    p->power = power;
+    const v3 q = vdivs(c, power);
+    p->rgb[0] = to_byte(q.x); p->rgb[1] = to_byte(q.y); p->rgb[2] = to_byte(q.z);
+    p->plane = 0;
+}
+
+static int is_photon_surface(const rt_material *m) { return (m->diffuse[0] + m->diffuse[1] + m->diffuse[2]) > 0; } /* p12 materials.h:50 */
+
+/* One photon path of the snapshot's emission loops (p12 main.cpp:298-316 direct only, 358-411 indirect,
+ * 415-466 caustics), seeded per path.  Appends to out[*n..cap); returns 0 when an append found the map full. */
+static int photon_path(const rt_scene_desc *sc, const rt_photon_params *pp, int which, uint64_t path,
+                       rt_photon *out, uint32_t cap, uint64_t *n, orc_stats *st)
+{
+    const rt_light *light = &sc->lights[0];
+    orc_rng rng;
+    orc_rng_set_sequence(&rng, path, pp->seed ^ (which == RT_MAP_CAUSTICS ? 0x43415553ULL : 0x50484F54ULL));
+    ray_t ray;
+    v3 c;
+    light_random_photon(light, &rng, &ray, &c);
+    const int direct_only = which == RT_MAP_GLOBAL && (pp->flags & (RT_PM_DIRECT | RT_PM_MONTE_CARLO));
+    int firstHit = 1;
+    for (int seg = 0; seg < pp->max_segments; ++seg) {
+        ray.p = vadd(ray.p, vscale(ray.d, 0.0002f));
+        hit_t h; hit_init(&h);
+        if (!trace_ray(sc, ray, &h, st) || h.light) return 1;
+        const rt_material *m = &sc->materials[sc->nodes[h.node].material];
+        if (direct_only) {
+            if (!is_photon_surface(m)) return 1;
+            if (*n >= cap) return 0;
+            photon_set(&out[(*n)++], h.p, ray.d, c);
+            return 1;
+        }
+        orc_surface s;
+        vst(s.p, h.p); vst(s.n, vnormalize(h.n)); vst(s.v, vneg(vnormalize(ray.d))); s.front = h.front;
+        v3 newDir = V3(0, 0, 0), mult = V3(0, 0, 0);
+        float prob = 0.0f;
+        int lobe = 0;
+        const int bounce = p12_mtl_generate(m, &s, &rng, &newDir, &mult, &prob, &lobe);
+        if (firstHit) {
+            if (which == RT_MAP_CAUSTICS) { if (!bounce || lobe == P12_DIFFUSE) return 1; }
+            else if (!bounce || ((pp->flags & RT_PM_CAUSTICS) && lobe != P12_DIFFUSE)) return 1;
+            firstHit = 0;
+        } else {
+            if (is_photon_surface(m)) {
+                if (*n >= cap) return 0;
+                photon_set(&out[(*n)++], h.p, ray.d, c);
+                if (which == RT_MAP_CAUSTICS) return 1;
+            }
+            if (!bounce) return 1;
+        }
+        ray.d = newDir;
+        ray.p = h.p;
+        c = vmul(c, vdivs(mult, prob));
+    }
+    return 1;
+}
+
+int orc_photons_emit(const rt_scene_desc *sc, const rt_photon_params *pp, int which, uint64_t path_begin, uint64_t path_count,
+                     rt_photon *out, uint32_t capacity, uint64_t *n_stored, uint64_t *paths_run, orc_stats *st)
+{
+    if (!sc || !pp || !out || sc->n_lights < 1 || sc->lights[0].type != RT_LIGHT_POINT) return RT_ERR_INVALID;
+    uint64_t n = 0, p = path_begin;
+    if (which == RT_MAP_GLOBAL && !(pp->flags & (RT_PM_DIRECT | RT_PM_MONTE_CARLO | RT_PM_INDIRECT))) path_count = 0;
+    if (which == RT_MAP_CAUSTICS && !(pp->flags & RT_PM_CAUSTICS)) path_count = 0;
+    for (; p < path_begin + path_count; ++p)
+        if (!photon_path(sc, pp, which, p, out, capacity, &n, st)) { ++p; break; }
+    if (n_stored) *n_stored = n;
+    if (paths_run) *paths_run = p - path_begin;
+    return RT_OK;
+}
+
+/* BalanceSegment (src/photonmap.h:202-264); ph and bal are 1-based */
+static void balance_segment(rt_photon *ph, rt_photon *bal, v3 boxMin, v3 boxMax, int index, int start, int end)
+{
+    int median = 1;
+    while ((4 * median) <= (end - start + 1)) median += median;
+    if ((3 * median) <= (end - start + 1)) { median += median; median += start - 1; }
+    else median = end - median + 1;
+    int axis = 2;
+    const v3 boxDif = vsub(boxMax, boxMin);
+    if (boxDif.x > boxDif.y) { if (boxDif.x > boxDif.z) axis = 0; }
+    else if (boxDif.y > boxDif.z) axis = 1;
+    int left = start, right = end;
+    while (right > left) {
+        const float v = ph[right].pos[axis];
+        int i = left - 1, j = right;
+        while (ph[++i].pos[axis] < v) {}
+        while (ph[--j].pos[axis] > v && j > left) {}
+        while (i < j) {
+            rt_photon t = ph[i]; ph[i] = ph[j]; ph[j] = t;
+            while (ph[++i].pos[axis] < v) {}
+            while (ph[--j].pos[axis] > v && j > left) {}
+        }
+        rt_photon t = ph[i]; ph[i] = ph[right]; ph[right] = t;
+        if (i >= median) right = i - 1;
+        if (i <= median) left = i + 1;
+    }
+    bal[index] = ph[median];
+    bal[index].plane = (uint8_t)axis;
+    if (median > start) {
+        if (start < median - 1) {
+            v3 tMax = boxMax;
+            (&tMax.x)[axis] = bal[index].pos[axis];
+            balance_segment(ph, bal, boxMin, tMax, 2 * index, start, median - 1);
+        } else bal[2 * index] = ph[start];
+    }
+    if (median < end) {
+        if (median + 1 < end) {
+            v3 tMin = boxMin;
+            (&tMin.x)[axis] = bal[index].pos[axis];
+            balance_segment(ph, bal, tMin, boxMax, 2 * index + 1, median + 1, end);
+        } else bal[2 * index + 1] = ph[end];
+    }
+}
+
+/* ScalePhotonPowers(1/n) + PrepareForIrradianceEstimation (src/photonmap.h:82,176-198; p12 main.cpp:412-413).
+ * in: n photons in emission order; tree: n photons in heap order (node i at tree[i-1]). */
+int orc_photon_build(const rt_photon *in, uint32_t n, rt_photon *tree)
+{
+    if (n == 0) return RT_OK;
+    rt_photon *ph = (rt_photon *)calloc((size_t)n + 1, sizeof *ph), *bal = (rt_photon *)calloc((size_t)n + 1, sizeof *bal);
+    if (!ph || !bal) { free(ph); free(bal); return RT_ERR_INVALID; }
+    memcpy(ph + 1, in, (size_t)n * sizeof *ph);
+    const float scale = 1.0f / (float)(int)n;
+    for (uint32_t i = 1; i <= n; ++i) ph[i].power *= scale;
+    /* the bounding box starts from slot 0, which holds no photon: the origin is always inside it */
+    v3 boxMin = vld(ph[0].pos), boxMax = boxMin;
+    for (uint32_t i = 1; i <= n; ++i) {
+        if (boxMin.x > ph[i].pos[0]) boxMin.x = ph[i].pos[0];
+        if (boxMax.x < ph[i].pos[0]) boxMax.x = ph[i].pos[0];
+        if (boxMin.y > ph[i].pos[1]) boxMin.y = ph[i].pos[1];
+        if (boxMax.y < ph[i].pos[1]) boxMax.y = ph[i].pos[1];
+        if (boxMin.z > ph[i].pos[2]) boxMin.z = ph[i].pos[2];
+        if (boxMax.z < ph[i].pos[2]) boxMax.z = ph[i].pos[2];
+    }
+    balance_segment(ph, bal, boxMin, boxMax, 1, 1, (int)n);
+    memcpy(tree, bal + 1, (size_t)n * sizeof *tree);
+    free(ph); free(bal);
+    return RT_OK;
+}
+
+typedef struct {
+    v3 pos, normal;
+    int found;
+    float dist2[RT_GATHER_MAX_PHOTONS + 1];
+    uint32_t photon[RT_GATHER_MAX_PHOTONS + 1]; /* node indices instead of copies: same order, same sums */
+    uint64_t visits;
+} nearest_t;
+
+/* LocatePhotons<true> with ellipticity 1 (src/photonmap.h:339-414); tree is 1-based here */
+static void locate_photons(const rt_photon *tree, int half, nearest_t *np, int index)
+{
+    const rt_photon *p = &tree[index];
+    const int axis = p->plane & 3;
+    ++np->visits;
+    if (index < half) {
+        const float dist = (&np->pos.x)[axis] - p->pos[axis];
+        if (dist > 0) {
+            locate_photons(tree, half, np, 2 * index + 1);
+            if (dist * dist < np->dist2[0]) locate_photons(tree, half, np, 2 * index);
+        } else {
+            locate_photons(tree, half, np, 2 * index);
+            if (dist * dist < np->dist2[0]) locate_photons(tree, half, np, 2 * index + 1);
+        }
+    }
+    const v3 dif = vsub(vld(p->pos), np->pos);
+    const float dist2 = vlen2(dif);
+    if (dist2 < np->dist2[0]) {
+        if (vdot(vld(p->dir), np->normal) >= 0) return;
+        const int maxPhotons = RT_GATHER_MAX_PHOTONS;
+        if (np->found < maxPhotons) {
+            np->found++;
+            np->dist2[np->found] = dist2;
+            np->photon[np->found] = (uint32_t)index;
+            if (np->found == maxPhotons) {
+                const int half_found = np->found >> 1;
+                for (int k = half_found; k >= 1; k--) {
+                    int parent = k;
+                    const uint32_t tp = np->photon[k];
+                    const float td2 = np->dist2[k];
+                    while (parent <= half_found) {
+                        int j = parent + parent;
+                        if (j < np->found && np->dist2[j] < np->dist2[j + 1]) j++;
+                        if (td2 >= np->dist2[j]) break;
+                        np->dist2[parent] = np->dist2[j];
+                        np->photon[parent] = np->photon[j];
+                        parent = j;
+                    }
+                    np->photon[parent] = tp;
+                    np->dist2[parent] = td2;
+                }
+            }
+        } else {
+            int parent = 1, j = 2;
+            while (j <= np->found) {
+                if (j < np->found && np->dist2[j] < np->dist2[j + 1]) j++;
+                if (dist2 > np->dist2[j]) break;
+                np->dist2[parent] = np->dist2[j];
+                np->photon[parent] = np->photon[j];
+                parent = j;
+                j <<= 1;
+            }
+            np->photon[parent] = (uint32_t)index;
+            np->dist2[parent] = dist2;
+            np->dist2[0] = np->dist2[1];
+        }
+    }
+}
+
+/* EstimateIrradiance<128>(irrad, dir, radius, pos, normal, 1) (src/photonmap.h:98,268-309).
+ * tree0 = node 1 (heap order, as orc_photon_build returns it). Returns the nodes visited. */
+uint64_t orc_photon_irradiance(const rt_photon *tree0, uint32_t n, const float pos[3], const float normal[3], float radius, float irrad[3])
+{
+    irrad[0] = irrad[1] = irrad[2] = 0.0f;
+    if (n == 0) return 0;
+    const rt_photon *tree = tree0 - 1;
+    nearest_t np;
+    np.pos = vld(pos); np.normal = vld(normal); np.found = 0; np.visits = 0;
+    np.dist2[0] = radius * radius;
+    locate_photons(tree, (int)n / 2 - 1, &np, 1);
+    v3 sum = V3(0, 0, 0);
+    for (int i = 1; i <= np.found; i++) {
+        const rt_photon *p = &tree[np.photon[i]];
+        const v3 power = vscale(V3(p->rgb[0] / 255.0f, p->rgb[1] / 255.0f, p->rgb[2] / 255.0f), p->power);
+        sum = vadd(sum, vscale(power, 1.0f));
+    }
+    if (np.found > 0) {
+        const float area = PI_F * np.dist2[0];
+        if (area > 0) sum = vscale(sum, 1.0f / area);
+    }
+    vst(irrad, sum);
+    return np.visits;
+}
+
+/* the maps the Whitted-style shader reads (Renderer::SetPhotonMap / SetCausticsMap, p12 renderer.h:225-228) */
+static const rt_photon *g_map[2] = { NULL, NULL };
+static uint32_t g_map_n[2] = { 0, 0 };
+void orc_set_photon_map(int which, const rt_photon *tree, uint32_t n)
+{
+    if (which < 0 || which > 1) return;
+    g_map[which] = tree; g_map_n[which] = n;
+}
+
 /* ------------------------------------------------------------------------- */
 /* Whitted-style shading of the project-12 snapshot (p12 = project12.zip)     */
 /* ------------------------------------------------------------------------- */
@@ -880,8 +1258,8 @@ static v3 w_illuminate(const wctx *C, const rt_light *l, v3 P, v3 *dir)
         const float jitterRadius = fmodf(offsetY + C->halton[3][i % (size_t)P16], 1.0f);
         const float diskTheta = (float)(jitterTheta * 2.0f * M_PI);
         const float diskRadius = sqrtf(jitterRadius);
-        const float x = diskRadius * cosf(diskTheta);
-        const float y = diskRadius * sinf(diskTheta);
+        const float x = (float)(diskRadius * cos((double)diskTheta)); /* double cos/sin: see light_random_photon */
+        const float y = (float)(diskRadius * sin((double)diskTheta));
         const v3 destination = vadd(vadd(pos, vscale(u, x * l->size)), vscale(v, y * l->size));
         const v3 sampleRayDir = vsub(destination, P);
         if (w_shadow(C, P, sampleRayDir, 1.0f) == 1.0f) ++numHits;
@@ -918,7 +1296,8 @@ static v3 whitted_shade(const wctx *C, const wshade *s, const rt_material *m)
     const v3 diffuseColor = vld(m->diffuse);
     const v3 specular = vld(m->specular);
     const float gloss = m->glossiness;
-    for (uint32_t i = 0; i < sc->n_lights; ++i) {
+    const int pm = C->prm->photon_flags;
+    for (uint32_t i = 0; i < sc->n_lights && !(pm & RT_PM_DIRECT); ++i) {
         const rt_light *l = &sc->lights[i];
         v3 lightDir;
         const v3 lightIntensity = w_illuminate(C, l, s->p, &lightDir);
@@ -930,12 +1309,27 @@ static v3 whitted_shade(const wctx *C, const wshade *s, const rt_material *m)
         const float k = (float)((gloss + 2.0f) / (8.0f * M_PI));
         final = vadd(final, vscale(vmul(vscale(vscale(specular, k), powf(blinnTerm, gloss)), lightIntensity), geometryTerm));
     }
+    /* irradiance from the photon maps (p12 materials.cpp:49-70); the reference also runs the estimate for a
+     * specular surface that is no photon surface and then drops the result */
+    const float pos3[3] = { s->p.x, s->p.y, s->p.z }, nrm3[3] = { normal.x, normal.y, normal.z };
+    if ((pm & (RT_PM_DIRECT | RT_PM_INDIRECT)) && is_photon_surface(m)) {
+        float e[3];
+        const uint64_t v = orc_photon_irradiance(g_map[0], g_map_n[0], pos3, nrm3, C->prm->gather_radius, e);
+        if (C->st) { C->st->gathers++; C->st->photon_visits += v; }
+        final = vadd(final, vmul(vscale(diffuseColor, (float)(1.0f / M_PI)), vld(e)));
+    }
+    if ((pm & RT_PM_CAUSTICS) && is_photon_surface(m)) {
+        float e[3];
+        const uint64_t v = orc_photon_irradiance(g_map[1], g_map_n[1], pos3, nrm3, C->prm->gather_radius, e);
+        if (C->st) { C->st->gathers++; C->st->photon_visits += v; }
+        final = vadd(final, vmul(vscale(diffuseColor, (float)(1.0f / M_PI)), vld(e)));
+    }
     if (!(s->bounce < C->prm->max_bounces)) return final; /* CanBounce (p12 renderer.h:180) */
 
     const int ps = C->p_sample;
     const int P16 = C->prm->halton_period;
     /* Monte-Carlo indirect light, first two bounces (p12 materials.cpp:74-103) */
-    if ((diffuseColor.x + diffuseColor.y + diffuseColor.z) > 0.0f && s->bounce < 2) {
+    if (!(pm & RT_PM_INDIRECT) && (diffuseColor.x + diffuseColor.y + diffuseColor.z) > 0.0f && s->bounce < 2) {
         const float phiOffset = orc_rng_float(C->rng);
         const float thetaOffset = orc_rng_float(C->rng);
         const float phi = (float)(2.0f * M_PI * fmodf(C->halton[0][ps % P16] + phiOffset, 1.0f));
@@ -1154,6 +1548,7 @@ static void *worker(void *arg)
     pthread_mutex_lock(&J->mu);
     J->stats.closest += st.closest; J->stats.shadow += st.shadow; J->stats.paths += st.paths;
     J->stats.box_tests += st.box_tests; J->stats.tri_tests += st.tri_tests; J->stats.node_visits += st.node_visits;
+    J->stats.gathers += st.gathers; J->stats.photon_visits += st.photon_visits;
     pthread_mutex_unlock(&J->mu);
     return NULL;
 }

@@ -38,7 +38,7 @@ float orc_halton(int index, int base);                              /* rng.h:103
 void orc_camera_derive(const rt_camera *cam, float out[12]);
 
 /* Renderer::TraceRay / TraceShadowRay (src/main.cpp:16-125) */
-typedef struct orc_stats { uint64_t closest, shadow, paths, box_tests, tri_tests, node_visits; } orc_stats;
+typedef struct orc_stats { uint64_t closest, shadow, paths, box_tests, tri_tests, node_visits, gathers, photon_visits; } orc_stats;
 int orc_trace(const rt_scene_desc *sc, const float ray6[6], rt_hit *hit, orc_stats *st);
 int orc_trace_shadow(const rt_scene_desc *sc, const float ray6[6], float t_max, orc_stats *st);
 
@@ -60,6 +60,21 @@ void orc_trace_path(const rt_scene_desc *sc, const float ray6[6], orc_rng *rng,
  * the tile shard given in prm; out pointers are full-frame host planes. */
 int orc_render(const rt_scene_desc *sc, const rt_camera *cam, const rt_render_params *prm,
                rt_frame_out *out, int n_threads, int y0, int y1, orc_stats *st);
+
+/* Photon maps (src/photonmap.h:38-414) and the emission loops of the project-12 snapshot (its main.cpp:292-470),
+ * with one PCG stream per photon path (see rt_photon_params in the ABI header).
+ * orc_photons_emit runs paths [path_begin, path_begin+path_count) in order and stops early when an append finds
+ * `capacity` photons stored already; *paths_run = paths started. */
+int orc_photons_emit(const rt_scene_desc *sc, const rt_photon_params *pp, int which, uint64_t path_begin, uint64_t path_count,
+                     rt_photon *out, uint32_t capacity, uint64_t *n_stored, uint64_t *paths_run, orc_stats *st);
+/* PointLight::RandomPhoton (src/lights.h:92-124) and the snapshot's MtlBlinn::GenerateSample (p12 materials.h:82-193) */
+void orc_light_random_photon(const rt_light *l, orc_rng *rng, float ray6[6], float c3[3]);
+int orc_p12_mtl_generate(const rt_material *m, const orc_surface *s, orc_rng *rng, orc_sample *out);
+int orc_photon_build(const rt_photon *in, uint32_t n, rt_photon *tree);
+uint64_t orc_photon_irradiance(const rt_photon *tree, uint32_t n, const float pos[3], const float normal[3], float radius,
+                               float irrad[3]);
+/* the maps orc_render's Whitted-style shader reads when prm->photon_flags != 0 (not copied) */
+void orc_set_photon_map(int which, const rt_photon *tree, uint32_t n);
 
 /* sRGB + 8-bit quantisation (cyColor.h:98,324-325) */
 void orc_resolve_pixel(const float linear[3], int srgb, uint8_t rgb[3]);

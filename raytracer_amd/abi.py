@@ -65,7 +65,19 @@ class RenderParams(C.Structure):
     _fields_ = [("mode", C.c_int32), ("min_spp", C.c_int32), ("max_spp", C.c_int32),
                 ("delta_max", C.c_float), ("max_bounces", C.c_int32), ("bias", C.c_float),
                 ("halton_period", C.c_int32), ("tile_size", C.c_int32), ("tile_rank", C.c_int32),
-                ("tile_world", C.c_int32), ("seed", C.c_uint64)]
+                ("tile_world", C.c_int32), ("seed", C.c_uint64), ("photon_flags", C.c_int32),
+                ("gather_radius", C.c_float)]
+
+
+class PhotonParams(C.Structure):
+    _fields_ = [("flags", C.c_int32), ("n_global", C.c_uint32), ("n_caustic", C.c_uint32),
+                ("max_segments", C.c_int32), ("seed", C.c_uint64)]
+
+
+PHOTON_DTYPE = np.dtype([("pos", "<f4", 3), ("power", "<f4"), ("dir", "<f4", 3), ("rgb", "u1", 3), ("plane", "u1")])
+assert PHOTON_DTYPE.itemsize == 32
+RT_PM_DIRECT, RT_PM_INDIRECT, RT_PM_CAUSTICS, RT_PM_MONTE_CARLO = 1, 2, 4, 8
+RT_MAP_GLOBAL, RT_MAP_CAUSTICS = 0, 1
 
 
 class FrameOut(C.Structure):
@@ -85,7 +97,8 @@ class HitBrief(C.Structure):
 
 class Counters(C.Structure):
     _fields_ = [("closest_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("camera_paths", C.c_uint64),
-                ("box_tests", C.c_uint64), ("tri_tests", C.c_uint64), ("kernel_ms", C.c_double),
+                ("box_tests", C.c_uint64), ("tri_tests", C.c_uint64), ("gathers", C.c_uint64),
+                ("photon_visits", C.c_uint64), ("kernel_ms", C.c_double),
                 ("trace_kernel_ms", C.c_double), ("trace_launches", C.c_uint32), ("phase_cycles", C.c_uint64 * 16)]
 
 
@@ -99,7 +112,8 @@ assert HIT_BRIEF_DTYPE.itemsize == C.sizeof(HitBrief)
 def default_params(**kw):
     """The constants the reference compiles in (src/main.cpp:93,107,164,220,273-274,369)."""
     p = RenderParams(mode=RT_MODE_PATH, min_spp=128, max_spp=128, delta_max=0.01, max_bounces=50,
-                     bias=0.002, halton_period=16, tile_size=16, tile_rank=0, tile_world=1, seed=7)
+                     bias=0.002, halton_period=16, tile_size=16, tile_rank=0, tile_world=1, seed=7,
+                     photon_flags=0, gather_radius=3.0)
     for k, v in kw.items():
         if not hasattr(p, k):
             raise AttributeError(k)

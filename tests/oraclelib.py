@@ -15,7 +15,8 @@ class Rng(C.Structure):
 
 
 class Stats(C.Structure):
-    _fields_ = [(n, C.c_uint64) for n in ("closest", "shadow", "paths", "box_tests", "tri_tests", "node_visits")]
+    _fields_ = [(n, C.c_uint64) for n in ("closest", "shadow", "paths", "box_tests", "tri_tests", "node_visits",
+                                              "gathers", "photon_visits")]
 
 
 class Surface(C.Structure):
@@ -67,6 +68,17 @@ def _load(name):
     L.orc_render.argtypes = [C.POINTER(abi.SceneDesc), C.POINTER(abi.Camera), C.POINTER(abi.RenderParams),
                              C.POINTER(abi.FrameOut), C.c_int, C.c_int, C.c_int, C.POINTER(Stats)]
     L.orc_resolve_pixel.argtypes = [abi.f32p, C.c_int, abi.u8p]
+    u64p = C.POINTER(C.c_uint64)
+    L.orc_photons_emit.argtypes = [C.POINTER(abi.SceneDesc), C.POINTER(abi.PhotonParams), C.c_int, C.c_uint64, C.c_uint64,
+                                   C.c_void_p, C.c_uint32, u64p, u64p, C.POINTER(Stats)]
+    L.orc_photon_build.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+    L.orc_photon_irradiance.argtypes = [C.c_void_p, C.c_uint32, abi.f32p, abi.f32p, C.c_float, abi.f32p]
+    L.orc_photon_irradiance.restype = C.c_uint64
+    L.orc_light_random_photon.argtypes = [C.POINTER(abi.Light), C.POINTER(Rng), abi.f32p, abi.f32p]
+    L.orc_light_random_photon.restype = None
+    L.orc_p12_mtl_generate.argtypes = [C.POINTER(abi.Material), C.POINTER(Surface), C.POINTER(Rng), C.POINTER(Sample)]
+    L.orc_set_photon_map.argtypes = [C.c_int, C.c_void_p, C.c_uint32]
+    L.orc_set_photon_map.restype = None
     return L
 
 
@@ -140,6 +152,47 @@ def trace_paths(scene, rays, seed, params):
         L.orc_trace_path(C.byref(scene.desc), rays[i].ctypes.data_as(abi.f32p), C.byref(rng), C.byref(params),
                          out[i].ctypes.data_as(abi.f32p), None)
     return out
+
+
+def photons_emit(scene, pp, which, path_begin=0, path_count=1 << 40, capacity=None):
+    """Photons of paths [path_begin, path_begin+path_count) in path order, at most `capacity`; also (stored, paths run)."""
+    cap = capacity if capacity is not None else (pp.n_caustic if which == abi.RT_MAP_CAUSTICS else pp.n_global)
+    out = np.zeros(max(1, cap), abi.PHOTON_DTYPE)
+    n, paths = C.c_uint64(), C.c_uint64()
+    rc = lib().orc_photons_emit(C.byref(scene.desc), C.byref(pp), which, path_begin, path_count, out.ctypes.data, cap,
+                                C.byref(n), C.byref(paths), None)
+    assert rc == 0, rc
+    return out[:n.value], paths.value
+
+
+def photon_build(raw):
+    raw = np.ascontiguousarray(raw)
+    tree = np.zeros(len(raw), abi.PHOTON_DTYPE)
+    assert lib().orc_photon_build(raw.ctypes.data, len(raw), tree.ctypes.data) == 0
+    return tree
+
+
+def photon_irradiance(tree, pos, normal, radius):
+    tree = np.ascontiguousarray(tree)
+    pos = np.ascontiguousarray(pos, np.float32)
+    normal = np.ascontiguousarray(normal, np.float32)
+    out = np.zeros((len(pos), 3), np.float32)
+    L = lib()
+    for i in range(len(pos)):
+        L.orc_photon_irradiance(tree.ctypes.data, len(tree), pos[i].ctypes.data_as(abi.f32p),
+                                normal[i].ctypes.data_as(abi.f32p), radius, out[i].ctypes.data_as(abi.f32p))
+    return out
+
+
+def fill_photon_maps(scene, pp):
+    """Both maps as the serial reference loop fills them; returns {which: tree} and keeps them set for render()."""
+    maps = {}
+    for which in (abi.RT_MAP_GLOBAL, abi.RT_MAP_CAUSTICS):
+        raw, _ = photons_emit(scene, pp, which)
+        maps[which] = photon_build(raw)
+        lib().orc_set_photon_map(which, maps[which].ctypes.data, len(maps[which]))
+        lib(fast=True).orc_set_photon_map(which, maps[which].ctypes.data, len(maps[which]))
+    return maps
 
 
 def psnr(a, b):

@@ -175,3 +175,101 @@ def test_whitted_images(name):
         b0 = abi.default_params(seed=seed, min_spp=mn, max_spp=mx, delta_max=float(g["delta"]), max_bounces=0,
                                 mode=abi.RT_MODE_WHITTED)
         assert np.abs(O.render(s, b0, w, h).linear - fr.linear).max() > 0.05
+
+
+def photon_words(a):
+    """32-byte photon records as [n, 8] words, the form the fixtures hold them in."""
+    return np.ascontiguousarray(a).view(np.uint32).reshape(-1, 8)
+
+
+def pm_params(g):
+    seed, ng, nc, seg, flags = [int(x) for x in g["params"][-5:]] if len(g["params"]) > 5 else [int(x) for x in g["params"]]
+    return abi.PhotonParams(flags=flags, n_global=ng, n_caustic=nc, max_segments=seg, seed=seed)
+
+
+@pytest.mark.parametrize("name", ["photons_a_indirect_caustics", "photons_a_direct"])
+def test_photon_maps(name):
+    """Photon emission (one PCG stream per path), the balanced kd-tree and EstimateIrradiance<128> against the
+    project-12 snapshot's PhotonMap / RandomPhoton / GenerateSample - bit for bit."""
+    g = O.load_golden(name)
+    s = O.scene_from_golden(g)
+    seed, ng, nc, seg, flags = [int(x) for x in g["params"]]
+    pp = abi.PhotonParams(flags=flags, n_global=ng, n_caustic=nc, max_segments=seg, seed=seed)
+    for which, key in ((abi.RT_MAP_GLOBAL, "global"), (abi.RT_MAP_CAUSTICS, "caustic")):
+        raw, paths = O.photons_emit(s, pp, which)
+        ref_raw = g[f"pm_{key}_raw"]
+        assert len(raw) == len(ref_raw)
+        if len(raw) == 0:
+            continue
+        assert paths == int(g["pm_paths"][which]), "photon paths needed to fill the map"
+        assert np.array_equal(photon_words(raw), ref_raw), f"{key}: emitted photons"
+        tree = O.photon_build(raw)
+        assert np.array_equal(photon_words(tree), g[f"pm_{key}_tree"]), f"{key}: balanced kd-tree"
+        # chunked emission gives the same photons as one serial run (what the multi-GPU split relies on)
+        parts = [O.photons_emit(s, pp, which, b, 1000, capacity=len(raw))[0] for b in range(0, paths, 1000)]
+        assert np.array_equal(photon_words(np.concatenate(parts))[:len(raw)], ref_raw)
+        col = 0 if which == abi.RT_MAP_GLOBAL else 3
+        e = O.photon_irradiance(tree, g["pm_query"][:, :3], g["pm_query"][:, 3:], float(g["radius"]))
+        assert_bits_equal(e, g["pm_irradiance"][:, col:col + 3], f"{key}: irradiance estimates")
+        assert (e > 0).any()
+
+
+@pytest.mark.parametrize("name", ["whitted_pm_a_64x36_b5", "whitted_pm_a_64x36_b0", "whitted_pd_a_64x36_b5"])
+def test_whitted_photon_images(name):
+    """The Whitted-style shader reading the photon maps (indirect + caustics as the snapshot ships, and direct
+    light from the map) against images of the snapshot - bit for bit."""
+    g = O.load_golden(name)
+    s = O.scene_from_golden(g)
+    seed, mn, mx, w, h, bounces, ng, nc, seg, flags = [int(x) for x in g["params"]]
+    pp = abi.PhotonParams(flags=flags, n_global=ng, n_caustic=nc, max_segments=seg, seed=seed)
+    maps = O.fill_photon_maps(s, pp)
+    assert np.array_equal(photon_words(maps[0]), g["pm_global_tree"])
+    if flags & abi.RT_PM_CAUSTICS:
+        assert np.array_equal(photon_words(maps[1]), g["pm_caustic_tree"])
+    prm = abi.default_params(seed=seed, min_spp=mn, max_spp=mx, delta_max=float(g["delta"]), max_bounces=bounces,
+                             mode=abi.RT_MODE_WHITTED, photon_flags=flags, gather_radius=3.0)
+    fr = O.render(s, prm, w, h)
+    assert np.array_equal(fr.object_id, g["object_id"]), "primary-hit ids"
+    assert_bits_equal(fr.z, g["z"], "z-buffer")
+    assert_bits_equal(fr.linear, g["linear"], "linear radiance")
+    assert np.array_equal(fr.rgb, g["rgb"]), "8-bit image"
+    assert fr.stats.gathers > 0
+
+
+def test_photon_emission_and_scatter_samplers():
+    """PointLight::RandomPhoton and the snapshot's MtlBlinn::GenerateSample (the photon scattering sampler),
+    value for value, including the number of random draws each call consumes."""
+    g = O.load_golden("kat_photon_a")
+    s = O.scene_from_golden(g)
+    seed = int(g["seed"])
+    L = O.lib()
+    rng = O.Rng()
+    for i, ref in enumerate(g["ph_emit"]):
+        L.orc_rng_set_sequence(C.byref(rng), i, seed ^ 0x50484F54)
+        r, c = np.zeros(6, np.float32), np.zeros(3, np.float32)
+        L.orc_light_random_photon(C.byref(s.desc.lights[0]), C.byref(rng), r.ctypes.data_as(abi.f32p), c.ctypes.data_as(abi.f32p))
+        assert_bits_equal(np.concatenate([r, c]), ref, f"RandomPhoton {i}")
+    inp, front, gen, fl = g["ph_smp_in"], g["ph_smp_front"], g["ph_smp_gen"], g["ph_smp_flags"]
+    f32 = np.float32
+
+    def unit(v):  # Vec3f::Normalize: (x*x + y*y + z*z), sqrt, three divisions
+        return (v / np.sqrt(f32(f32(v[0] * v[0]) + f32(v[1] * v[1])) + f32(v[2] * v[2]), dtype=f32)).astype(f32)
+
+    lobes = set()
+    for i in range(len(inp)):
+        su = O.Surface()
+        su.p[:] = inp[i, :3].tolist()
+        su.n[:] = unit(inp[i, 3:6]).tolist()
+        su.v[:] = (-unit(inp[i, 6:9])).tolist()
+        su.front = int(front[i])
+        for m in range(gen.shape[1]):
+            L.orc_rng_set_sequence(C.byref(rng), i + 1, seed ^ (0x2000 + m))
+            o = O.Sample()
+            ok = L.orc_p12_mtl_generate(C.byref(s.desc.materials[m]), C.byref(su), C.byref(rng), C.byref(o))
+            assert ok == fl[i, m, 0], (i, m)
+            assert L.orc_rng_u32(C.byref(rng)) == int(fl[i, m, 2]) & 0xFFFFFFFF, f"draws consumed {i} {m}"
+            if ok:
+                assert o.lobe == fl[i, m, 1]
+                lobes.add(o.lobe)
+                assert_bits_equal(np.array(list(o.dir) + list(o.mult) + [o.prob], f32), gen[i, m], f"GenerateSample {i} {m}")
+    assert lobes == {1, 2, 4}
