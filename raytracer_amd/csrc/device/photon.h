@@ -1,0 +1,449 @@
+// Photon maps on the GPU: emission and scattering of photon paths, and the k-nearest-photon
+// irradiance estimate over the left-balanced kd-tree.
+//   PointLight::RandomPhoton            src/lights.h:92-124
+//   MtlBlinn::GenerateSample (snapshot) project12.zip src/materials.h:82-193   (p12 below)
+//   emission loops                      p12 src/main.cpp:292-470
+//   PhotonMap::AddPhoton / SetPower     src/photonmap.h:148-172
+//   PhotonMap::IrradianceEstimate       src/photonmap.h:268-309
+//   PhotonMap::LocatePhotons            src/photonmap.h:339-414
+//
+// The snapshot's lights.h and materials.h call cos / sin / pow / sqrt from inside class bodies
+// that are compiled before <math.h> adds the float overloads, so those calls run in double and
+// the product with them is narrowed once; the arithmetic below does the same.
+#pragma once
+#include "kernels.h"
+
+namespace rtd {
+
+constexpr float kInvPiF = (float)(1.0f / M_PI);
+constexpr double kEightPi = 8.0f * M_PI;
+constexpr double kTwoPi = 2.0f * M_PI;
+RT_DEV float sum3(const float *c) { return c[0] + c[1] + c[2]; }
+
+// sin and cos of x in [0, 2 pi] in double: quadrant reduction against a two-part pi/2, then the
+// classic minimax polynomials on [-pi/4, pi/4].  Errors stay below one ulp of double, which is
+// invisible once the result is narrowed to float.
+RT_DEV void dsincos(double x, double &s, double &c)
+{
+    const double k = __builtin_rint(x * 0.63661977236758134308);
+    const double r = (x - k * 1.57079632673412561417e+00) - k * 6.07710050650619224932e-11;
+    const double z = r * r;
+    const double ps = -1.66666666666666324348e-01 + z * (8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 +
+                      z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10))));
+    const double pc = 4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 +
+                      z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11))));
+    const double sr = r + r * z * ps;
+    const double cr = (1.0 - 0.5 * z) + z * z * pc;
+    const int q = (int)k & 3;
+    s = (q == 0) ? sr : (q == 1) ? cr : (q == 2) ? -sr : -cr;
+    c = (q == 0) ? cr : (q == 1) ? -sr : (q == 2) ? -cr : sr;
+}
+// (float)(a * cos(t)), (float)(a * sin(t)) with a, t float: the product is formed in double
+RT_DEV void scaled_sincos(float a, float t, float &as, float &ac)
+{
+    double s, c;
+    dsincos((double)t, s, c);
+    as = (float)((double)a * s);
+    ac = (float)((double)a * c);
+}
+
+// PointLight::RandomPhoton (src/lights.h:92-124): 4 draws
+RT_DEV void light_random_photon(const rt_light &l, Rng &rng, Ray &r, V3 &c)
+{
+    float randU = rng_float(rng);
+    float randV = rng_float(rng);
+    const float theta = (float)(kTwoPi * randU);
+    const float posZ = l.size * (1.0f - 2.0f * randV);
+    const float rProj = fsqrt(l.size * l.size - posZ * posZ);
+    float posX, posY;
+    scaled_sincos(rProj, theta, posY, posX);
+    const V3 position = ld3(l.position);
+    const V3 rayPos = mk(posX, posY, posZ) + position;
+    r.p = rayPos;
+    randU = rng_float(rng);
+    randV = rng_float(rng);
+    const float phi = (float)(kTwoPi * randU);
+    const float cosTheta = randV;
+    const float sinTheta = fsqrt(1.0f - cosTheta * cosTheta);
+    float dirX, dirY;
+    scaled_sincos(sinTheta, phi, dirY, dirX);
+    const V3 norm = normalize(rayPos - position);
+    V3 u, v;
+    orthonormals(norm, u, v);
+    r.d = (u * dirX + v * dirY) + norm * cosTheta;
+    c = ((((ld3(l.intensity) * 8.0f) * (float)M_PI) * l.size) * l.size) * cosTheta;
+}
+
+// The snapshot's MtlBlinn::GenerateSample (p12 materials.h:82-193): 3 draws unless absorbed.
+// n = unit shading normal, v = unit view vector.  Returns the `bounce` flag of the emission loops.
+RT_DEV bool p12_mtl_generate(const rt_material &m, V3 Ns, V3 V, int front, Rng &rng, V3 &dir, V3 &mult, float &prob, int &lobe)
+{
+    float pd, ps, pt;
+    lobe_probs(m, pd, ps, pt);
+    const float randomNum = rng_float(rng);
+    if (randomNum < pd) {
+        lobe = LOBE_DIFFUSE;
+        mult = ld3(m.diffuse);
+        prob = pd;
+        const float r1 = rng_float(rng);
+        const float r2 = rng_float(rng);
+        const float z = fsqrt(r1);
+        const float sinTheta = fsqrt(1.0f - r1);
+        const float phi = (float)(kTwoPi * r2);
+        float x, y;
+        scaled_sincos(sinTheta, phi, y, x);
+        V3 u, v;
+        orthonormals(Ns, u, v);
+        dir = (u * x + v * y) + Ns * z;
+        return true;
+    }
+    if (!(randomNum < pd + ps + pt)) return false;
+    const bool spec = randomNum < pd + ps;
+    const V3 N = (spec || front) ? Ns : -Ns;
+    lobe = spec ? LOBE_SPECULAR : LOBE_TRANSMISSION;
+    prob = spec ? ps : pt;
+    const float r1 = rng_float(rng);
+    const float r2 = rng_float(rng);
+    const float phi = (float)(kTwoPi * r1);
+    const float cosTheta = (float)pow((double)r2, (double)(1.0f / (m.glossiness + 1.0f)));
+    const float sinTheta = fsqrt(1.0f - cosTheta * cosTheta);
+    float x, y;
+    scaled_sincos(sinTheta, phi, y, x);
+    V3 u, v;
+    orthonormals(N, u, v);
+    const V3 h = (u * x + v * y) + N * cosTheta;
+    const V3 refl = (h * 2.0f) * dot(V, h) - V;
+    if (spec) {
+        dir = refl;
+        mult = ld3(m.specular) * dot(dir, Ns);
+        return dot(dir, Ns) > 0.0f;
+    }
+    const float ratio = front ? 1.0f / m.ior : m.ior;
+    const float cos_i = dot(V, h);
+    const float sin_t_sq = (ratio * ratio) * (1.0f - cos_i * cos_i);
+    if (sin_t_sq > 1.0f) { // total internal reflection
+        lobe = LOBE_SPECULAR;
+        dir = refl;
+        mult = ld3(m.refraction) * fabsf(dot(dir, Ns));
+        return dot(dir, N) > 0.0f;
+    }
+    const float cos_t = fsqrt(1.0f - sin_t_sq);
+    dir = (-V) * ratio + h * (ratio * cos_i - cos_t);
+    mult = ld3(m.refraction) * fabsf(dot(dir, Ns));
+    return dot(dir, N) < 0.0f;
+}
+
+RT_DEV bool is_photon_surface(const rt_material &m) { return sum3(m.diffuse) > 0.0f; } // p12 materials.h:50
+
+// PhotonData::SetPower + AddPhoton (src/photonmap.h:148-172): one 32-byte record, two 16-byte stores
+RT_DEV void photon_store(rt_photon *dst, V3 pos, V3 dir, V3 c)
+{
+    float power = c.x;
+    if (power < c.y) power = c.y;
+    if (power < c.z) power = c.z;
+    const V3 q = c / power;
+    const uint32_t rgb = (uint32_t)to_byte(q.x) | ((uint32_t)to_byte(q.y) << 8) | ((uint32_t)to_byte(q.z) << 16);
+    float4 *d = (float4 *)dst;
+    d[0] = make_float4(pos.x, pos.y, pos.z, power);
+    d[1] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(rgb));
+}
+
+constexpr uint64_t kSeedGlobalMap = 0x50484F54ULL, kSeedCausticsMap = 0x43415553ULL;
+
+// One lane = one photon path at a time (paths come from the launch's work queue, so a wave
+// stays full although paths are 1..max_segments rays long); one trip of the loop = one ray.
+// The photons a path stores must land where the serial loop of the reference would have put
+// them, so the launch runs twice: WRITE = false counts the photons of every path, the host
+// scans the counts into offsets, WRITE = true traces the same paths again (same streams, same
+// arithmetic) and writes photon `seq` of path `i` to out[offsets[i] + seq] if that is below
+// `capacity`.
+template <bool WRITE, int LEVELS>
+__global__ __launch_bounds__(kBlock, 4) void k_photon_paths(DScene S, rt_photon_params P, int which, uint64_t path_begin,
+                                                            uint32_t n_paths, uint32_t *__restrict__ counts,
+                                                            const uint32_t *__restrict__ offsets, uint64_t base,
+                                                            rt_photon *__restrict__ out, uint64_t capacity, DCounters *ctr,
+                                                            unsigned long long *queue)
+{
+    extern __shared__ uint32_t lds[];
+    const LaneStack st = lane_stack(lds, S);
+    const uint32_t lane = threadIdx.x & 63u;
+    PathTally pt;
+    Tally<false> tl;
+    uint32_t paths = 0;
+    const rt_light &light = S.lights[0];
+    const bool caustics_map = which == RT_MAP_CAUSTICS;
+    const bool direct_only = !caustics_map && (P.flags & (RT_PM_DIRECT | RT_PM_MONTE_CARLO));
+    const uint64_t seed = P.seed ^ (caustics_map ? kSeedCausticsMap : kSeedGlobalMap);
+
+    WorkQueue wq(queue, n_paths);
+    bool alive = false, firstHit = true;
+    uint32_t item = 0, seq = 0;
+    int seg = 0;
+    Rng rng; rng.state = 0; rng.inc = 1;
+    Ray ray{mk(0, 0, 0), mk(0, 0, 1)};
+    V3 c = mk(0, 0, 0);
+
+    for (;;) {
+        const uint64_t need = __ballot(!alive);
+        if (need != 0) {
+            wq.refill(lane);
+            const uint64_t avail = wq.end - wq.next;
+            const uint32_t want = (uint32_t)__popcll(need);
+            const uint32_t take = avail < want ? (uint32_t)avail : want;
+            const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+            if (!alive && rank < take) {
+                item = (uint32_t)(wq.next + rank);
+                rng_set_sequence(rng, path_begin + item, seed);
+                light_random_photon(light, rng, ray, c);
+                firstHit = true; seq = 0; seg = 0;
+                alive = true;
+                ++paths;
+            }
+            wq.next += take;
+        }
+        if (!__any(alive)) {
+            if (wq.exhausted) break;
+            continue;
+        }
+        if (alive) {
+            bool go_on = false;
+            ray.p = ray.p + ray.d * 0.0002f;
+            Hit h;
+            ++pt.closest;
+            const bool hit = trace_closest<false, LEVELS>(S, ray, st, h, tl);
+            if (hit && h.node >= 0) { // a miss or a light ends the path
+                finish_hit(S, ray, h, false);
+                const rt_material &m = S.materials[S.nodes[h.node].material];
+                bool store = false;
+                V3 newDir = mk(0, 0, 0), mult = mk(0, 0, 0);
+                float prob = 1.0f;
+                int lobe = LOBE_NONE;
+                if (direct_only) store = is_photon_surface(m); // first hits only (p12 main.cpp:298-316)
+                else {
+                    const bool bounce = p12_mtl_generate(m, normalize(h.n), -normalize(ray.d), h.front, rng, newDir, mult, prob, lobe);
+                    if (firstHit) { // the first hit is never stored; it decides which map the path belongs to
+                        go_on = caustics_map ? (bounce && lobe != LOBE_DIFFUSE)
+                                             : (bounce && !((P.flags & RT_PM_CAUSTICS) && lobe != LOBE_DIFFUSE));
+                        firstHit = false;
+                    } else {
+                        store = is_photon_surface(m);
+                        go_on = bounce && !(caustics_map && store); // a caustic photon ends where it is stored
+                    }
+                }
+                if (store) {
+                    if (WRITE) {
+                        const uint64_t idx = base + offsets[item] + seq;
+                        if (idx < capacity) photon_store(out + idx, h.p, ray.d, c);
+                    }
+                    ++seq;
+                }
+                if (go_on) {
+                    ray.d = newDir;
+                    ray.p = h.p;
+                    c = c * (mult / prob);
+                }
+            }
+            ++seg;
+            if (!go_on || seg >= P.max_segments) {
+                if (!WRITE) counts[item] = seq;
+                alive = false;
+            }
+        }
+    }
+    flush_counters<false>(ctr, pt, tl, paths);
+}
+
+// ---- exclusive scan of the per-path photon counts (three small launches) ----
+constexpr uint32_t kScanTile = 1024; // elements per workgroup: 4 per thread
+__global__ __launch_bounds__(kBlock) void k_scan_tiles(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, uint32_t n,
+                                                       uint32_t *__restrict__ tile_sums)
+{
+    __shared__ uint32_t part[kBlock];
+    const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * 4;
+    uint32_t v[4], sum = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] = base + i < n ? in[base + i] : 0u; sum += v[i]; }
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (uint32_t o = 1; o < kBlock; o <<= 1) { // Hillis-Steele over the 256 thread sums
+        const uint32_t add = threadIdx.x >= o ? part[threadIdx.x - o] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += add;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - sum; // exclusive prefix of this thread within the tile
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { if (base + i < n) out[base + i] = run; run += v[i]; }
+    if (threadIdx.x == kBlock - 1) tile_sums[blockIdx.x] = part[kBlock - 1];
+}
+// one workgroup: exclusive scan of the tile sums in place, grand total to *total
+__global__ __launch_bounds__(kBlock) void k_scan_sums(uint32_t *__restrict__ tile_sums, uint32_t n_tiles, unsigned long long *total)
+{
+    __shared__ uint32_t part[kBlock];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t first = 0; first < n_tiles; first += kBlock) {
+        const uint32_t i = first + threadIdx.x;
+        const uint32_t v = i < n_tiles ? tile_sums[i] : 0u;
+        part[threadIdx.x] = v;
+        __syncthreads();
+        for (uint32_t o = 1; o < kBlock; o <<= 1) {
+            const uint32_t add = threadIdx.x >= o ? part[threadIdx.x - o] : 0u;
+            __syncthreads();
+            part[threadIdx.x] += add;
+            __syncthreads();
+        }
+        if (i < n_tiles) tile_sums[i] = carry + part[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 0) carry += part[kBlock - 1];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+__global__ __launch_bounds__(kBlock) void k_scan_add(uint32_t *__restrict__ out, uint32_t n, const uint32_t *__restrict__ tile_sums)
+{
+    const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * 4;
+    const uint32_t add = tile_sums[blockIdx.x];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (base + i < n) out[base + i] += add;
+}
+
+// ---- irradiance estimate ----
+// EstimateIrradiance<128>(irrad, dir, radius, pos, normal, 1) (src/photonmap.h:98,268-309) with
+// LocatePhotons<true> (src/photonmap.h:339-414).  The reference recurses: near child, then the far
+// child if the split plane is closer than the current search radius, then the node's own photon.
+// The loop below visits the nodes in exactly that order with an explicit stack (one entry per
+// level: node, which child is the far one, squared plane distance), keeps the reference's array
+// of found photons and its max-heap as indices into the map, and sums their powers in array order,
+// so the estimate has the reference's bits.  `tree` is the balanced map, node 1 first.
+constexpr int kGatherK = RT_GATHER_MAX_PHOTONS;
+constexpr uint32_t kFarIsLow = 0x80000000u, kFarDone = 0x40000000u;
+
+template <bool COUNT>
+RT_DEV V3 photon_irradiance(const rt_photon *tree0, uint32_t n, V3 pos, V3 normal, float radius, LaneStack st, uint32_t &visits)
+{
+    if (n == 0) return mk(0, 0, 0);
+    const GF4 tree = (GF4)(const void *)tree0 - 2; // node i = tree[2 i], tree[2 i + 1]
+    const int half = (int)n / 2 - 1;               // nodes below this index are treated as internal (src/photonmap.h:197,346)
+    float d2[kGatherK + 1];
+    uint32_t id[kGatherK + 1];
+    int found = 0;
+    d2[0] = radius * radius;
+    int sp = 0;
+    uint32_t cur = 1;
+    for (;;) {
+        while ((int)cur < half) { // descend towards the query point
+            const f4 q0 = tree[2 * cur], q1 = tree[2 * cur + 1];
+            const uint32_t axis = (__float_as_uint(q1.w) >> 24) & 3u;
+            const float split = axis == 0 ? q0.x : (axis == 1 ? q0.y : q0.z);
+            const float qa = axis == 0 ? pos.x : (axis == 1 ? pos.y : pos.z);
+            const float dist = qa - split;
+            const bool high_first = dist > 0.0f;
+            st.push(sp, cur | (high_first ? kFarIsLow : 0u), dist * dist);
+            ++sp;
+            if (COUNT) ++visits;
+            cur = high_first ? 2 * cur + 1 : 2 * cur;
+        }
+        if (COUNT) ++visits;
+        uint32_t node = cur;
+        bool descend = false;
+        for (;;) {
+            { // the node's own photon (src/photonmap.h:357-413)
+                const f4 q0 = tree[2 * node], q1 = tree[2 * node + 1];
+                const V3 dif = mk(q0.x, q0.y, q0.z) - pos;
+                const float dist2 = len2(dif);
+                if (dist2 < d2[0] && !(dot(mk(q1.x, q1.y, q1.z), normal) >= 0.0f)) {
+                    if (found < kGatherK) {
+                        ++found;
+                        d2[found] = dist2;
+                        id[found] = node;
+                        if (found == kGatherK) { // build the max-heap
+                            const int half_found = found >> 1;
+                            for (int k = half_found; k >= 1; --k) {
+                                int parent = k;
+                                const uint32_t tp = id[k];
+                                const float td2 = d2[k];
+                                while (parent <= half_found) {
+                                    int j = parent + parent;
+                                    if (j < found && d2[j] < d2[j + 1]) ++j;
+                                    if (td2 >= d2[j]) break;
+                                    d2[parent] = d2[j];
+                                    id[parent] = id[j];
+                                    parent = j;
+                                }
+                                id[parent] = tp;
+                                d2[parent] = td2;
+                            }
+                        }
+                    } else { // replace the farthest
+                        int parent = 1, j = 2;
+                        while (j <= found) {
+                            if (j < found && d2[j] < d2[j + 1]) ++j;
+                            if (dist2 > d2[j]) break;
+                            d2[parent] = d2[j];
+                            id[parent] = id[j];
+                            parent = j;
+                            j <<= 1;
+                        }
+                        id[parent] = node;
+                        d2[parent] = dist2;
+                        d2[0] = d2[1];
+                    }
+                }
+            }
+            // back up: the parent's far child if it can still hold something closer, else the parent's own photon
+            bool up = false;
+            while (sp > 0) {
+                uint32_t data; float plane2;
+                st.pop(sp - 1, data, plane2);
+                const uint32_t parent = data & 0x3FFFFFFFu;
+                if (!(data & kFarDone) && plane2 < d2[0]) {
+                    st.push(sp - 1, data | kFarDone, plane2);
+                    cur = (data & kFarIsLow) ? 2 * parent : 2 * parent + 1;
+                    descend = true;
+                    break;
+                }
+                --sp;
+                node = parent;
+                up = true;
+                break;
+            }
+            if (descend || !up) break;
+        }
+        if (!descend) break;
+    }
+    V3 sum = mk(0, 0, 0);
+    for (int i = 1; i <= found; ++i) {
+        const f4 q0 = tree[2 * id[i]], q1 = tree[2 * id[i] + 1];
+        const uint32_t rgb = __float_as_uint(q1.w);
+        const V3 col = mk((float)(rgb & 255u) / 255.0f, (float)((rgb >> 8) & 255u) / 255.0f, (float)((rgb >> 16) & 255u) / 255.0f);
+        sum = sum + col * q0.w; // Color24::ToColor() * power, constant filter
+    }
+    if (found > 0) {
+        const float area = kPi * d2[0];
+        if (area > 0.0f) sum = sum * (1.0f / area);
+    }
+    return sum;
+}
+
+__global__ __launch_bounds__(kBlock) void k_photon_irradiance(DScene S, const rt_photon *tree, uint32_t n_photons,
+                                                              const float *__restrict__ pos3, const float *__restrict__ nrm3,
+                                                              int n, float radius, float *__restrict__ out3, DCounters *ctr)
+{
+    extern __shared__ uint32_t lds[];
+    const LaneStack st = lane_stack(lds, S);
+    uint32_t visits = 0, gathers = 0;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const V3 e = photon_irradiance<true>(tree, n_photons, ld3(pos3 + (size_t)i * 3), ld3(nrm3 + (size_t)i * 3), radius, st, visits);
+        out3[(size_t)i * 3] = e.x; out3[(size_t)i * 3 + 1] = e.y; out3[(size_t)i * 3 + 2] = e.z;
+        ++gathers;
+    }
+    const uint64_t g = wave_sum(gathers), v = wave_sum(visits);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&ctr->gathers, (unsigned long long)g);
+        atomicAdd(&ctr->photon_visits, (unsigned long long)v);
+    }
+}
+
+} // namespace rtd

@@ -53,6 +53,8 @@ struct DScene {
     int32_t stack_levels; // BVH stack entries a lane may need (deepest mesh + 2), 0 without meshes
     int32_t lds_levels;   // of which in LDS; the rest in stack_overflow
     uint2 *stack_overflow; // [(stack_levels - lds_levels)][threads of the largest grid]
+    const rt_photon *pmap[2]; // balanced photon maps (global, caustics), node 1 first; null when not built
+    uint32_t pmap_n[2];
 };
 
 // Frame constants (camera + sampling), by value in the kernel arguments.
@@ -67,11 +69,12 @@ struct DFrame {
     float bias;
     int32_t halton_period;
     uint64_t seed;
-    float halton[4][64];
+    int32_t photon_flags; // RT_PM_* bits the Whitted-style shader honours
+    float gather_radius;
 };
 
 struct DCounters {
-    unsigned long long closest, shadow, paths, box_tests, tri_tests;
+    unsigned long long closest, shadow, paths, box_tests, tri_tests, gathers, photon_visits;
     unsigned long long phase[16]; // diagnostic: wave clock cycles per phase (RT_PROFILE_PHASES builds)
 };
 

@@ -14,7 +14,7 @@
 // from the work queue.  Lanes of a wave therefore stay busy although one sample may need 5 and
 // its neighbour 400 rays.
 #pragma once
-#include "kernels.h"
+#include "photon.h"
 
 namespace rtd {
 
@@ -33,9 +33,6 @@ struct WFrame {
     uint32_t meta; // material index | front << 20 | pending combination << 24
 };
 
-constexpr float kInvPiF = (float)(1.0f / M_PI);
-constexpr double kEightPi = 8.0f * M_PI;
-constexpr double kTwoPi = 2.0f * M_PI;
 
 // Blinn-Phong term of one light (p12 materials.cpp:33-47)
 RT_DEV void whitted_light_term(WFrame &f, const rt_material &m, V3 lightIntensity, V3 lightDir)
@@ -62,16 +59,14 @@ RT_DEV Ray whitted_fan_ray(const rt_light &L, V3 P, const float *__restrict__ ha
     const float jr = frac_sum(offY, halton[192 + hi]);
     const float theta = (float)((double)(jt * 2.0f) * M_PI);
     const float radius = fsqrt(jr);
-    const float x = radius * cosf(theta);
-    const float y = radius * sinf(theta);
+    float x, y; // diskRadius * cos(diskTheta), formed in double (see photon.h)
+    scaled_sincos(radius, theta, y, x);
     const V3 dest = (pos + u * (x * L.size)) + v * (y * L.size);
     Ray r;
     r.d = dest - P;
     r.p = P + r.d * 0.0002f; // ShadeInfo::TraceShadowRay (p12 main.cpp:126-130)
     return r;
 }
-
-RT_DEV float sum3(const float *c) { return c[0] + c[1] + c[2]; }
 
 // (x u + y v) + z n (p12 materials.cpp:96,125,153)
 RT_DEV V3 whitted_frame(V3 u, V3 v, V3 n, float x, float y, float z) { return (u * x + v * y) + n * z; }
@@ -103,8 +98,9 @@ __global__ __launch_bounds__(kBlock, 4) void k_whitted(DScene S, DFrame F, const
     const uint32_t lane = threadIdx.x & 63u;
     PathTally pt;
     Tally<COUNT> tl;
-    uint32_t paths = 0;
+    uint32_t paths = 0, gathers = 0, visits = 0;
     const int period = F.halton_period;
+    const int pm = F.photon_flags;
 
     WorkQueue wq(queue, n_items);
     int state = W_IDLE;
@@ -257,7 +253,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_whitted(DScene S, DFrame F, const
             V3 child_dir = mk(0, 0, 0);
             int child = -1; // pending combination of the child ray to spawn, -1 = none
             if (stage == STG_LIGHT) {
-                if (l >= S.n_lights) { stage = STG_AFTER; continue; }
+                if (l >= S.n_lights || (pm & RT_PM_DIRECT)) { stage = STG_AFTER; continue; } // no light loop when the map holds the direct light
                 const rt_light &L = S.lights[l];
                 if (L.type == RT_LIGHT_AMBIENT) { // p12 lights.h:33, materials.cpp:28-31
                     cur.final = cur.final + ld3(m.diffuse) * ld3(L.intensity);
@@ -281,12 +277,25 @@ __global__ __launch_bounds__(kBlock, 4) void k_whitted(DScene S, DFrame F, const
                 break;
             }
             if (stage == STG_AFTER) {
+                // irradiance from the photon maps (p12 materials.cpp:49-70).  The reference also runs the estimate for a
+                // specular surface that is no photon surface and drops the result; that lookup is skipped here.
+                if (pm != 0 && is_photon_surface(m)) {
+                    const V3 kd = ld3(m.diffuse) * kInvPiF;
+                    if (pm & (RT_PM_DIRECT | RT_PM_INDIRECT)) {
+                        cur.final = cur.final + kd * photon_irradiance<COUNT>(S.pmap[0], S.pmap_n[0], cur.p, cur.n, F.gather_radius, st, visits);
+                        ++gathers;
+                    }
+                    if (pm & RT_PM_CAUSTICS) {
+                        cur.final = cur.final + kd * photon_irradiance<COUNT>(S.pmap[1], S.pmap_n[1], cur.p, cur.n, F.gather_radius, st, visits);
+                        ++gathers;
+                    }
+                }
                 if (!(depth < F.max_bounces)) { ret = cur.final; retDist = cur.dist; state = W_RET; continue; } // CanBounce
                 stage = STG_MC;
             }
             if (stage == STG_MC) { // Monte-Carlo indirect light on the first two bounces (p12 materials.cpp:74-103)
                 stage = STG_REFL;
-                if (sum3(m.diffuse) > 0.0f && depth < 2) {
+                if (!(pm & RT_PM_INDIRECT) && sum3(m.diffuse) > 0.0f && depth < 2) {
                     const float phiOffset = rng_float(rng);
                     const float thetaOffset = rng_float(rng);
                     const float phi = (float)(kTwoPi * frac_sum(halton[ps_h], phiOffset));
@@ -355,6 +364,13 @@ __global__ __launch_bounds__(kBlock, 4) void k_whitted(DScene S, DFrame F, const
         }
     }
     flush_counters<COUNT>(ctr, pt, tl, paths);
+    if (pm != 0) {
+        const uint64_t g = wave_sum(gathers), v = wave_sum(visits);
+        if (lane == 0) {
+            atomicAdd(&ctr->gathers, (unsigned long long)g);
+            if (COUNT) atomicAdd(&ctr->photon_visits, (unsigned long long)v);
+        }
+    }
 }
 
 } // namespace rtd

@@ -2,6 +2,7 @@
 // Host-side control only; the arithmetic lives in device/*.h.
 #include "device/pathsm.h"
 #include "device/whitted.h"
+#include "host/photon_map.h"
 #include "rt_mi355x.h"
 
 #include <algorithm>
@@ -75,6 +76,10 @@ struct rt_ctx {
     int ray_levels = 1; // hierarchy levels that have children
     DeviceBuf d_rgb, d_z, d_cnt, d_id, d_lin; // internal planes when the caller wants host output
     DeviceBuf d_q_in, d_q_aux, d_q_out;       // batch queries
+    // photon maps: balanced trees the shader reads, and scratch of the emission launches
+    DeviceBuf d_pmap[2], d_ph_raw, d_ph_counts, d_ph_offsets, d_ph_tiles, d_ph_total;
+    uint32_t pmap_n[2] = {0, 0};
+    int pmap_flags = -1; // RT_PM_* bits the maps were filled with, -1 = not known (built from caller's photons)
     std::vector<int32_t> active_host;
     int active_key[5] = {-1, -1, -1, -1, -1};
     rt_counters counters{};
@@ -147,6 +152,15 @@ int validate_params(rt_ctx *ctx, const rt_render_params *p)
         return ctx->fail(RT_ERR_INVALID, "the Whitted-style shader takes max_bounces 0..%d (its ray tree grows as 3^bounces)", kMaxWhittedBounces);
     if (p->halton_period < 1 || p->halton_period > 64) return ctx->fail(RT_ERR_INVALID, "halton_period must be 1..64");
     if (p->tile_size < 1) return ctx->fail(RT_ERR_INVALID, "tile_size < 1");
+    if (p->mode == RT_MODE_WHITTED && p->photon_flags != 0) {
+        if (p->photon_flags & ~(RT_PM_DIRECT | RT_PM_INDIRECT | RT_PM_CAUSTICS | RT_PM_MONTE_CARLO))
+            return ctx->fail(RT_ERR_INVALID, "unknown photon_flags bits 0x%x", p->photon_flags);
+        if (!(p->gather_radius > 0.0f)) return ctx->fail(RT_ERR_INVALID, "gather_radius must be > 0");
+        if ((p->photon_flags & (RT_PM_DIRECT | RT_PM_INDIRECT)) && ctx->pmap_n[RT_MAP_GLOBAL] == 0)
+            return ctx->fail(RT_ERR_STATE, "photon_flags ask for the global photon map, which has not been built (rt_photons_fill / rt_photons_build)");
+        if ((p->photon_flags & RT_PM_CAUSTICS) && ctx->pmap_n[RT_MAP_CAUSTICS] == 0)
+            return ctx->fail(RT_ERR_STATE, "photon_flags ask for the caustics photon map, which has not been built (rt_photons_fill / rt_photons_build)");
+    }
     if (p->tile_world < 1 || p->tile_rank < 0 || p->tile_rank >= p->tile_world)
         return ctx->fail(RT_ERR_INVALID, "need 0 <= tile_rank < tile_world");
     return RT_OK;
@@ -158,6 +172,8 @@ void fill_frame(const rt_ctx *ctx, const rt_render_params *p, DFrame &F)
     derive_camera(ctx->camera, F);
     F.min_spp = p->min_spp; F.max_spp = p->max_spp; F.delta_max = p->delta_max;
     F.max_bounces = p->max_bounces; F.bias = p->bias; F.halton_period = p->halton_period; F.seed = p->seed;
+    F.photon_flags = p->mode == RT_MODE_WHITTED ? p->photon_flags : 0;
+    F.gather_radius = p->gather_radius;
 }
 
 const void *paths_kernel(bool counting, int ray_levels, bool lockstep)
@@ -347,6 +363,10 @@ int rt_init(int device, rt_ctx **out)
                           (const void *)k_whitted<true, 1>, (const void *)k_whitted<true, 2>, (const void *)k_whitted<true, 5>,
                           (const void *)k_trace, (const void *)k_trace_shadow, (const void *)k_trace_paths})
         (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    for (const void *k : {(const void *)k_photon_paths<false, 1>, (const void *)k_photon_paths<false, 2>, (const void *)k_photon_paths<false, 5>,
+                          (const void *)k_photon_paths<true, 1>, (const void *)k_photon_paths<true, 2>, (const void *)k_photon_paths<true, 5>,
+                          (const void *)k_photon_irradiance})
+        (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
     ctx->n_cu = prop.multiProcessorCount;
@@ -527,6 +547,8 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc)
     memcpy(S.background, sc->background, 12);
     memcpy(S.environment, sc->environment, 12);
     ctx->mesh_bufs.swap(bufs);
+    ctx->pmap_n[0] = ctx->pmap_n[1] = 0; // photon maps belong to the scene they were traced in
+    ctx->pmap_flags = -1;
     ctx->scene = S;
     ctx->ray_levels = ray_levels;
     ctx->have_scene = true;
@@ -626,6 +648,7 @@ int rt_render(rt_ctx *ctx, const rt_render_params *prm, rt_frame_out *out)
             HIP_TRY(ctx, hipEventRecord(ctx->evk0, s));
             if (prm->mode == RT_MODE_WHITTED) {
                 const void *fn = whitted_kernel(ctx->counting, ctx->ray_levels);
+                for (int w = 0; w < 2; ++w) { ctx->scene.pmap[w] = ctx->pmap_n[w] ? ctx->d_pmap[w].as<rt_photon>() : nullptr; ctx->scene.pmap_n[w] = ctx->pmap_n[w]; }
                 int per_cu = 1;
                 HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kBlock, lds));
                 per_cu = std::max(1, std::min(per_cu, 8));
@@ -716,6 +739,7 @@ int rt_render(rt_ctx *ctx, const rt_render_params *prm, rt_frame_out *out)
     rt_counters &c = ctx->counters;
     c.closest_rays = dc.closest; c.shadow_rays = dc.shadow; c.camera_paths = dc.paths;
     c.box_tests = dc.box_tests; c.tri_tests = dc.tri_tests;
+    c.gathers = dc.gathers; c.photon_visits = dc.photon_visits;
     for (int i = 0; i < 16; ++i) c.phase_cycles[i] = dc.phase[i];
     c.kernel_ms = ms; c.trace_kernel_ms = trace_ms; c.trace_launches = launches;
     return RT_OK;
@@ -870,6 +894,252 @@ int rt_trace_paths(rt_ctx *ctx, const float *rays6, int n, uint64_t seed, const 
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(radiance3, ctx->d_q_out.p, (size_t)n * 12, hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));
+    return RT_OK;
+}
+
+} // extern "C"
+
+// ---- photon maps ----
+namespace {
+
+const void *photon_kernel(bool write, int ray_levels)
+{
+    if (ray_levels <= 1) return write ? (const void *)k_photon_paths<true, 1> : (const void *)k_photon_paths<false, 1>;
+    if (ray_levels == 2) return write ? (const void *)k_photon_paths<true, 2> : (const void *)k_photon_paths<false, 2>;
+    return write ? (const void *)k_photon_paths<true, 5> : (const void *)k_photon_paths<false, 5>;
+}
+
+// the kd-tree walk keeps one stack entry per tree level in the lanes' BVH stacks: make them deep enough
+int ensure_stack_levels(rt_ctx *ctx, int levels)
+{
+    DScene &S = ctx->scene;
+    if (levels <= S.stack_levels) return RT_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    S.stack_levels = levels;
+    S.lds_levels = std::min(S.stack_levels, ctx->lds_levels_max);
+    const size_t ovf_levels = (size_t)(S.stack_levels - S.lds_levels);
+    HIP_TRY(ctx, ctx->d_stack_ovf.reserve(std::max<size_t>(1, ovf_levels) * ctx->ovf_threads * sizeof(uint2) * rt_ctx::kMaxPools));
+    S.stack_overflow = ctx->d_stack_ovf.as<uint2>();
+    return RT_OK;
+}
+
+int validate_photon_params(rt_ctx *ctx, const rt_photon_params *p, int which)
+{
+    if (!p) return ctx->fail(RT_ERR_INVALID, "null photon params");
+    if (which != RT_MAP_GLOBAL && which != RT_MAP_CAUSTICS) return ctx->fail(RT_ERR_INVALID, "map must be RT_MAP_GLOBAL or RT_MAP_CAUSTICS");
+    if (p->flags & ~(RT_PM_DIRECT | RT_PM_INDIRECT | RT_PM_CAUSTICS | RT_PM_MONTE_CARLO)) return ctx->fail(RT_ERR_INVALID, "unknown photon flag bits 0x%x", p->flags);
+    if (p->max_segments < 1 || p->max_segments > 4096) return ctx->fail(RT_ERR_INVALID, "max_segments must be 1..4096");
+    return RT_OK;
+}
+
+bool map_enabled(int flags, int which)
+{
+    return which == RT_MAP_CAUSTICS ? (flags & RT_PM_CAUSTICS) != 0 : (flags & (RT_PM_DIRECT | RT_PM_INDIRECT | RT_PM_MONTE_CARLO)) != 0;
+}
+
+// paths [path_begin, path_begin + n_paths) -> photons at out[base ..], in path order; *stored = photons these paths store
+int emit_chunk(rt_ctx *ctx, const rt_photon_params *pp, int which, uint64_t path_begin, uint32_t n_paths, rt_photon *d_out,
+               uint64_t base, uint64_t capacity, uint64_t *stored)
+{
+    hipStream_t s = ctx->stream;
+    const uint32_t n_tiles = (n_paths + kScanTile - 1) / kScanTile;
+    HIP_TRY(ctx, ctx->d_ph_counts.reserve((size_t)n_paths * 4));
+    HIP_TRY(ctx, ctx->d_ph_offsets.reserve((size_t)n_paths * 4));
+    HIP_TRY(ctx, ctx->d_ph_tiles.reserve((size_t)n_tiles * 4));
+    HIP_TRY(ctx, ctx->d_ph_total.reserve(8));
+    const size_t lds = stack_lds_bytes(ctx->scene);
+    DScene a_scene = ctx->scene;
+    rt_photon_params a_pp = *pp;
+    uint32_t *a_counts = ctx->d_ph_counts.as<uint32_t>();
+    const uint32_t *a_offsets = ctx->d_ph_offsets.as<uint32_t>();
+    DCounters *a_ctr = ctx->d_counters.as<DCounters>();
+    unsigned long long *a_queue = ctx->d_queue.as<unsigned long long>();
+    for (int pass = 0; pass < 2; ++pass) {
+        const void *fn = photon_kernel(pass == 1, ctx->ray_levels);
+        int per_cu = 1;
+        HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kBlock, lds));
+        per_cu = std::max(1, std::min(per_cu, 8));
+        const dim3 grid((unsigned)std::min<uint64_t>(((uint64_t)n_paths + kBlock - 1) / kBlock, (uint64_t)ctx->n_cu * per_cu));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue.p, 0, kQueueBytes, s));
+        void *args[] = {&a_scene, &a_pp, &which, &path_begin, &n_paths, &a_counts, &a_offsets, &base, &d_out, &capacity, &a_ctr, &a_queue};
+        HIP_TRY(ctx, hipLaunchKernel(fn, grid, dim3(kBlock), args, lds, s));
+        if (pass == 0) {
+            hipLaunchKernelGGL(k_scan_tiles, dim3(n_tiles), dim3(kBlock), 0, s, ctx->d_ph_counts.as<uint32_t>(), ctx->d_ph_offsets.as<uint32_t>(),
+                               n_paths, ctx->d_ph_tiles.as<uint32_t>());
+            hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kBlock), 0, s, ctx->d_ph_tiles.as<uint32_t>(), n_tiles, ctx->d_ph_total.as<unsigned long long>());
+            hipLaunchKernelGGL(k_scan_add, dim3(n_tiles), dim3(kBlock), 0, s, ctx->d_ph_offsets.as<uint32_t>(), n_paths, ctx->d_ph_tiles.as<uint32_t>());
+            HIP_TRY(ctx, hipGetLastError());
+            unsigned long long total = 0;
+            HIP_TRY(ctx, hipMemcpyAsync(&total, ctx->d_ph_total.p, 8, hipMemcpyDeviceToHost, s));
+            HIP_TRY(ctx, hipStreamSynchronize(s));
+            *stored = total;
+            if (total == 0 || base >= capacity) break; // nothing to write
+        }
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int rt_photons_emit(rt_ctx *ctx, const rt_photon_params *pp, int which, uint64_t path_begin, uint64_t path_count,
+                    rt_photon *out, uint32_t capacity, uint64_t *n_stored, int device_memory)
+{
+    if (!ctx) return RT_ERR_INVALID;
+    if (!ctx->have_scene) return ctx->fail(RT_ERR_STATE, "no scene uploaded");
+    if (int rc = validate_photon_params(ctx, pp, which)) return rc;
+    if (!n_stored || (capacity > 0 && !out)) return ctx->fail(RT_ERR_INVALID, "null output");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    *n_stored = 0;
+    if (!map_enabled(pp->flags, which) || path_count == 0) return RT_OK;
+    rt_photon *d_out = out;
+    if (!device_memory) {
+        HIP_TRY(ctx, ctx->d_ph_raw.reserve(std::max<size_t>(1, capacity) * sizeof(rt_photon)));
+        d_out = ctx->d_ph_raw.as<rt_photon>();
+    }
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters.p, 0, sizeof(DCounters), s));
+    HIP_TRY(ctx, hipEventRecord(ctx->evk0, s));
+    const uint64_t kMaxChunk = 1ull << 24; // keeps the 32-bit offsets of a launch below 2^24 * max_segments
+    uint64_t stored = 0;
+    for (uint64_t first = 0; first < path_count; first += kMaxChunk) {
+        const uint32_t n = (uint32_t)std::min<uint64_t>(kMaxChunk, path_count - first);
+        uint64_t got = 0;
+        if (int rc = emit_chunk(ctx, pp, which, path_begin + first, n, d_out, stored, capacity, &got)) return rc;
+        stored += got;
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->evk1, s));
+    const uint64_t written = std::min<uint64_t>(stored, capacity);
+    if (!device_memory && written) HIP_TRY(ctx, hipMemcpyAsync(out, d_out, written * sizeof(rt_photon), hipMemcpyDeviceToHost, s));
+    DCounters dc{};
+    HIP_TRY(ctx, hipMemcpyAsync(&dc, ctx->d_counters.p, sizeof dc, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    *n_stored = stored;
+    float ms = 0;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->evk0, ctx->evk1));
+    ctx->counters = rt_counters{};
+    ctx->counters.closest_rays = dc.closest; // both passes: the rays actually traced
+    ctx->counters.camera_paths = dc.paths;
+    ctx->counters.kernel_ms = ms; ctx->counters.trace_kernel_ms = ms; ctx->counters.trace_launches = 2;
+    return RT_OK;
+}
+
+int rt_photons_build(rt_ctx *ctx, int which, const rt_photon *photons, uint32_t n, int device_memory)
+{
+    if (!ctx) return RT_ERR_INVALID;
+    if (!ctx->have_scene) return ctx->fail(RT_ERR_STATE, "no scene uploaded");
+    if (which != RT_MAP_GLOBAL && which != RT_MAP_CAUSTICS) return ctx->fail(RT_ERR_INVALID, "map must be RT_MAP_GLOBAL or RT_MAP_CAUSTICS");
+    if (n > 0 && !photons) return ctx->fail(RT_ERR_INVALID, "null photon array");
+    if (n > (1u << 30)) return ctx->fail(RT_ERR_INVALID, "at most 2^30 photons per map");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->pmap_n[which] = 0;
+    ctx->pmap_flags = -1;
+    if (n == 0) return RT_OK;
+    std::vector<rt_photon> raw;
+    const rt_photon *src = photons;
+    if (device_memory) {
+        raw.resize(n);
+        HIP_TRY(ctx, hipMemcpy(raw.data(), photons, (size_t)n * sizeof(rt_photon), hipMemcpyDeviceToHost));
+        src = raw.data();
+    }
+    for (uint32_t i = 0; i < n; ++i) {
+        const rt_photon &p = src[i];
+        if (!(std::isfinite(p.pos[0]) && std::isfinite(p.pos[1]) && std::isfinite(p.pos[2])))
+            return ctx->fail(RT_ERR_INVALID, "photon %u has a non-finite position", i); // the quick-select would not terminate
+    }
+    std::vector<rt_photon> tree;
+    rt::build_photon_tree(src, n, tree);
+    HIP_TRY(ctx, ctx->d_pmap[which].reserve((size_t)n * sizeof(rt_photon)));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_pmap[which].p, tree.data(), (size_t)n * sizeof(rt_photon), hipMemcpyHostToDevice));
+    int levels = 1;
+    while ((1u << levels) <= n) ++levels; // tree height
+    if (int rc = ensure_stack_levels(ctx, levels + 1)) return rc;
+    ctx->pmap_n[which] = n;
+    return RT_OK;
+}
+
+int rt_photons_fill(rt_ctx *ctx, const rt_photon_params *pp)
+{
+    if (!ctx) return RT_ERR_INVALID;
+    if (!ctx->have_scene) return ctx->fail(RT_ERR_STATE, "no scene uploaded");
+    if (int rc = validate_photon_params(ctx, pp, RT_MAP_GLOBAL)) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    double emit_ms = 0.0;
+    uint64_t rays = 0, paths_total = 0;
+    for (int which = 0; which < 2; ++which) {
+        const uint32_t cap = which == RT_MAP_CAUSTICS ? pp->n_caustic : pp->n_global;
+        if (!map_enabled(pp->flags, which) || cap == 0) {
+            if (int rc = rt_photons_build(ctx, which, nullptr, 0, 0)) return rc;
+            continue;
+        }
+        DeviceBuf raw;
+        HIP_TRY(ctx, raw.reserve((size_t)cap * sizeof(rt_photon)));
+        uint64_t stored = 0, path = 0, round = 1u << 16;
+        int barren = 0;
+        while (stored < cap) {
+            uint64_t got = 0;
+            if (int rc = rt_photons_emit(ctx, pp, which, path, round, raw.as<rt_photon>() + stored, (uint32_t)(cap - stored), &got, 1)) return rc;
+            emit_ms += ctx->counters.kernel_ms; rays += ctx->counters.closest_rays; paths_total += round;
+            path += round;
+            stored += std::min<uint64_t>(got, cap - stored);
+            // next round: what is still missing at the yield seen so far, with a little margin
+            const double yield = (double)std::max<uint64_t>(stored, 1) / (double)path;
+            round = (uint64_t)std::min<double>(1 << 24, std::max<double>(1 << 16, 1.05 * (double)(cap - stored) / yield + 1024));
+            barren = got == 0 ? barren + 1 : 0;
+            if (barren >= 8 && stored == 0) return ctx->fail(RT_ERR_UNSUPPORTED, "no photon stored after %llu paths: the scene has no surface that takes photons for this map", (unsigned long long)path);
+        }
+        if (int rc = rt_photons_build(ctx, which, raw.as<rt_photon>(), cap, 1)) return rc;
+    }
+    ctx->pmap_flags = pp->flags;
+    ctx->counters = rt_counters{};
+    ctx->counters.closest_rays = rays; ctx->counters.camera_paths = paths_total;
+    ctx->counters.kernel_ms = emit_ms; ctx->counters.trace_kernel_ms = emit_ms;
+    return RT_OK;
+}
+
+int rt_photons_download(rt_ctx *ctx, int which, rt_photon *dst, uint32_t *n)
+{
+    if (!ctx) return RT_ERR_INVALID;
+    if (which != RT_MAP_GLOBAL && which != RT_MAP_CAUSTICS) return ctx->fail(RT_ERR_INVALID, "map must be RT_MAP_GLOBAL or RT_MAP_CAUSTICS");
+    if (!n) return ctx->fail(RT_ERR_INVALID, "null count");
+    *n = ctx->pmap_n[which];
+    if (!dst || *n == 0) return RT_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpy(dst, ctx->d_pmap[which].p, (size_t)*n * sizeof(rt_photon), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_photons_irradiance(rt_ctx *ctx, int which, const float *pos3, const float *normal3, int n, float radius, float *irradiance3)
+{
+    if (!ctx) return RT_ERR_INVALID;
+    if (!ctx->have_scene) return ctx->fail(RT_ERR_STATE, "no scene uploaded");
+    if (which != RT_MAP_GLOBAL && which != RT_MAP_CAUSTICS) return ctx->fail(RT_ERR_INVALID, "map must be RT_MAP_GLOBAL or RT_MAP_CAUSTICS");
+    if (n < 0 || (n > 0 && (!pos3 || !normal3 || !irradiance3))) return ctx->fail(RT_ERR_INVALID, "bad query arrays");
+    if (!(radius > 0.0f)) return ctx->fail(RT_ERR_INVALID, "radius must be > 0");
+    if (n == 0) return RT_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    HIP_TRY(ctx, ctx->d_q_in.reserve((size_t)n * 12));
+    HIP_TRY(ctx, ctx->d_q_aux.reserve((size_t)n * 12));
+    HIP_TRY(ctx, ctx->d_q_out.reserve((size_t)n * 12));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_q_in.p, pos3, (size_t)n * 12, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_q_aux.p, normal3, (size_t)n * 12, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters.p, 0, sizeof(DCounters), s));
+    HIP_TRY(ctx, hipEventRecord(ctx->evk0, s));
+    hipLaunchKernelGGL(k_photon_irradiance, batch_grid(ctx, n), dim3(kBlock), stack_lds_bytes(ctx->scene), s, ctx->scene,
+                       ctx->d_pmap[which].as<rt_photon>(), ctx->pmap_n[which], ctx->d_q_in.as<float>(), ctx->d_q_aux.as<float>(), n, radius,
+                       ctx->d_q_out.as<float>(), ctx->d_counters.as<DCounters>());
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->evk1, s));
+    HIP_TRY(ctx, hipMemcpyAsync(irradiance3, ctx->d_q_out.p, (size_t)n * 12, hipMemcpyDeviceToHost, s));
+    DCounters dc{};
+    HIP_TRY(ctx, hipMemcpyAsync(&dc, ctx->d_counters.p, sizeof dc, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    if (int rc = batch_time(ctx)) return rc;
+    ctx->counters.gathers = dc.gathers; ctx->counters.photon_visits = dc.photon_visits;
     return RT_OK;
 }
 

@@ -21,6 +21,7 @@ SYMBOLS = (
     "rt_trace", "rt_trace_shadow", "rt_trace_brief", "rt_trace_paths", "rt_get_counters", "rt_set_counting",
     "rt_scene_load_xml", "rt_scene_from_xml_string", "rt_scene_host_desc", "rt_scene_host_camera",
     "rt_scene_host_free", "rt_scene_host_set_mesh", "rt_bvh_build", "rt_free",
+    "rt_photons_emit", "rt_photons_build", "rt_photons_fill", "rt_photons_download", "rt_photons_irradiance",
 )
 
 _lib = None
@@ -70,6 +71,12 @@ def load():
                                C.POINTER(abi.u32p), C.POINTER(C.c_uint32)]
     L.rt_free.argtypes = [vp]
     L.rt_free.restype = None
+    L.rt_photons_emit.argtypes = [vp, C.POINTER(abi.PhotonParams), C.c_int, C.c_uint64, C.c_uint64, vp, C.c_uint32,
+                                  C.POINTER(C.c_uint64), C.c_int]
+    L.rt_photons_build.argtypes = [vp, C.c_int, vp, C.c_uint32, C.c_int]
+    L.rt_photons_fill.argtypes = [vp, C.POINTER(abi.PhotonParams)]
+    L.rt_photons_download.argtypes = [vp, C.c_int, vp, C.POINTER(C.c_uint32)]
+    L.rt_photons_irradiance.argtypes = [vp, C.c_int, abi.f32p, abi.f32p, C.c_int, C.c_float, abi.f32p]
     _lib = L
     return L
 
@@ -227,6 +234,44 @@ class Context:
         out = np.zeros((len(rays), 3), np.float32)
         self._check(self._L.rt_trace_paths(self._h, rays.ctypes.data_as(abi.f32p), len(rays), seed, C.byref(params),
                                            out.ctypes.data_as(abi.f32p)))
+        return out
+
+    # ---- photon maps ----
+    def photons_emit(self, pp, which, path_begin, path_count, capacity, device_ptr=0):
+        """Photons of paths [path_begin, path_begin + path_count) in path order.  Returns (photons, stored) with at
+        most `capacity` photons; with device_ptr they are written to that device address and None is returned for them."""
+        n = C.c_uint64()
+        if device_ptr:
+            self._check(self._L.rt_photons_emit(self._h, C.byref(pp), which, path_begin, path_count, device_ptr, capacity, C.byref(n), 1))
+            return None, n.value
+        out = np.zeros(max(1, capacity), abi.PHOTON_DTYPE)
+        self._check(self._L.rt_photons_emit(self._h, C.byref(pp), which, path_begin, path_count, out.ctypes.data, capacity, C.byref(n), 0))
+        return out[:min(n.value, capacity)], n.value
+
+    def photons_build(self, which, photons=None, device_ptr=0, n=0):
+        if device_ptr:
+            self._check(self._L.rt_photons_build(self._h, which, device_ptr, n, 1))
+            return
+        photons = np.ascontiguousarray(photons, abi.PHOTON_DTYPE)
+        self._check(self._L.rt_photons_build(self._h, which, photons.ctypes.data, len(photons), 0))
+
+    def photons_fill(self, pp):
+        self._check(self._L.rt_photons_fill(self._h, C.byref(pp)))
+
+    def photons_download(self, which):
+        n = C.c_uint32()
+        self._check(self._L.rt_photons_download(self._h, which, None, C.byref(n)))
+        out = np.zeros(n.value, abi.PHOTON_DTYPE)
+        if n.value:
+            self._check(self._L.rt_photons_download(self._h, which, out.ctypes.data, C.byref(n)))
+        return out
+
+    def photons_irradiance(self, which, pos, normal, radius):
+        pos = np.ascontiguousarray(pos, np.float32)
+        normal = np.ascontiguousarray(normal, np.float32)
+        out = np.zeros((len(pos), 3), np.float32)
+        self._check(self._L.rt_photons_irradiance(self._h, which, pos.ctypes.data_as(abi.f32p), normal.ctypes.data_as(abi.f32p),
+                                                  len(pos), radius, out.ctypes.data_as(abi.f32p)))
         return out
 
     def close(self):

@@ -154,6 +154,9 @@ def trace_paths(scene, rays, seed, params):
     return out
 
 
+_KEEP = {}
+
+
 def photons_emit(scene, pp, which, path_begin=0, path_count=1 << 40, capacity=None):
     """Photons of paths [path_begin, path_begin+path_count) in path order, at most `capacity`; also (stored, paths run)."""
     cap = capacity if capacity is not None else (pp.n_caustic if which == abi.RT_MAP_CAUSTICS else pp.n_global)
@@ -187,6 +190,7 @@ def photon_irradiance(tree, pos, normal, radius):
 def fill_photon_maps(scene, pp):
     """Both maps as the serial reference loop fills them; returns {which: tree} and keeps them set for render()."""
     maps = {}
+    _KEEP["photon_maps"] = maps  # the oracle holds pointers into these arrays
     for which in (abi.RT_MAP_GLOBAL, abi.RT_MAP_CAUSTICS):
         raw, _ = photons_emit(scene, pp, which)
         maps[which] = photon_build(raw)

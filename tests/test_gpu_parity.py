@@ -209,6 +209,89 @@ def test_whitted_rejects_deep_recursion(ctx):
     assert e.value.code == abi.RT_ERR_INVALID
 
 
+def photon_words(a):
+    return np.ascontiguousarray(a).view(np.uint32).reshape(-1, 8)
+
+
+@pytest.mark.parametrize("name", ["photons_a_indirect_caustics", "photons_a_direct"])
+def test_photon_maps_vs_reference(ctx, name):
+    """Photon emission (k_photon_paths), the kd-tree build and the irradiance estimate (k_photon_irradiance)
+    against the project-12 snapshot's maps.  Emission goes through double sin/cos/pow whose device forms can
+    differ from glibc's in the last bit of a double, which is invisible in all but a vanishing share of the
+    photons; everything else is integer or IEEE float work and must be bit-exact."""
+    g = O.load_golden(name)
+    s = O.scene_from_golden(g)
+    seed, ng, nc, seg, flags = [int(x) for x in g["params"]]
+    pp = abi.PhotonParams(flags=flags, n_global=ng, n_caustic=nc, max_segments=seg, seed=seed)
+    ctx.upload(s.desc)
+    for which, key in ((abi.RT_MAP_GLOBAL, "global"), (abi.RT_MAP_CAUSTICS, "caustic")):
+        ref_raw, ref_tree = g[f"pm_{key}_raw"], g[f"pm_{key}_tree"]
+        paths = int(g["pm_paths"][which])
+        if len(ref_raw) == 0:
+            got, stored = ctx.photons_emit(pp, which, 0, 1000, 16)
+            assert stored == 0 and len(got) == 0
+            continue
+        got, stored = ctx.photons_emit(pp, which, 0, paths, len(ref_raw))
+        assert stored >= len(ref_raw) and len(got) == len(ref_raw)
+        same = (photon_words(got) == ref_raw).all(axis=1)
+        assert same.mean() >= 0.999, f"{key}: only {same.mean():.4f} of the emitted photons are bit-identical"
+        # split emission (what several GPUs do): concatenation in path order is the same list
+        parts, total = [], 0
+        for b in range(0, paths, 1500):
+            part, st = ctx.photons_emit(pp, which, b, min(1500, paths - b), len(ref_raw))
+            parts.append(part[:st])
+            total += st
+        assert total == stored
+        assert np.array_equal(photon_words(np.concatenate(parts))[:len(ref_raw)], photon_words(got))
+        # the tree from the reference's own photon list must be the reference's tree, node for node
+        ctx.photons_build(which, ref_raw.view(abi.PHOTON_DTYPE).reshape(-1))
+        assert np.array_equal(photon_words(ctx.photons_download(which)), ref_tree), f"{key}: balanced kd-tree"
+        col = 0 if which == abi.RT_MAP_GLOBAL else 3
+        e = ctx.photons_irradiance(which, g["pm_query"][:, :3], g["pm_query"][:, 3:], float(g["radius"]))
+        assert np.array_equal(bits(e), bits(g["pm_irradiance"][:, col:col + 3])), f"{key}: irradiance estimates"
+    # rt_photons_fill: rounds of paths until the maps are full
+    ctx.photons_fill(pp)
+    for which, key in ((abi.RT_MAP_GLOBAL, "global"), (abi.RT_MAP_CAUSTICS, "caustic")):
+        tree = ctx.photons_download(which)
+        assert len(tree) == len(g[f"pm_{key}_tree"])
+        if len(tree):
+            same = (photon_words(tree) == g[f"pm_{key}_tree"]).all(axis=1)
+            assert same.mean() >= 0.99, f"{key}: filled map differs from the reference's ({same.mean():.4f})"
+
+
+@pytest.mark.parametrize("name", ["whitted_pm_a_64x36_b5", "whitted_pm_a_64x36_b0", "whitted_pd_a_64x36_b5"])
+def test_whitted_photon_images_vs_reference(ctx, name):
+    g = O.load_golden(name)
+    s = O.scene_from_golden(g)
+    seed, mn, mx, w, h, bounces, ng, nc, seg, flags = [int(x) for x in g["params"]]
+    pp = abi.PhotonParams(flags=flags, n_global=ng, n_caustic=nc, max_segments=seg, seed=seed)
+    ctx.upload(s.desc)
+    ctx.set_camera(s.camera, w, h)
+    prm = abi.default_params(seed=seed, min_spp=mn, max_spp=mx, delta_max=float(g["delta"]), max_bounces=bounces,
+                             mode=abi.RT_MODE_WHITTED, photon_flags=flags, gather_radius=3.0)
+    with pytest.raises(lib.RtError) as e:  # maps not built yet
+        ctx.render(prm)
+    assert e.value.code == abi.RT_ERR_STATE
+    ctx.photons_fill(pp)
+    ctx.set_counting(True)
+    try:
+        fr = ctx.render(prm)
+        c = ctx.counters()
+    finally:
+        ctx.set_counting(False)
+    assert np.array_equal(fr.object_id, g["object_id"]), "primary-hit ids"
+    assert np.array_equal(bits(fr.z), bits(g["z"])), "z-buffer"
+    p = O.psnr(fr.rgb, g["rgb"])
+    assert p >= PSNR_MIN, f"PSNR {p:.2f} dB vs the reference image"
+    close = np.all(np.abs(fr.linear - g["linear"]) <= 1e-4 * np.maximum(1.0, np.abs(g["linear"])), axis=-1)
+    assert close.mean() >= 0.97, f"only {close.mean():.4f} of the pixels agree in linear radiance"
+    # the oracle counts the lookups the same way
+    O.fill_photon_maps(s, pp)
+    cpu = O.render(s, prm, w, h)
+    assert abs(int(c.gathers) - int(cpu.stats.gathers)) <= 5e-3 * cpu.stats.gathers
+    assert abs(int(c.photon_visits) - int(cpu.stats.photon_visits)) <= 1e-2 * cpu.stats.photon_visits
+
+
 def test_pipelines_agree(monkeypatch):
     """The lock-step path kernel (default), the wavefront pipeline (logic kernel + ray-list kernel) and
     the fused path kernel (ray-level regeneration in one launch) run the same per-path arithmetic:
