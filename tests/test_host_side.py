@@ -30,13 +30,23 @@ def test_library_exports_every_declared_symbol():
     assert L.rt_abi_version() == 2
 
 
-def test_struct_sizes_match_header():
-    assert C.sizeof(abi.Node) == 112
-    assert C.sizeof(abi.BvhNode) == 28
-    assert C.sizeof(abi.Material) == 80
-    assert C.sizeof(abi.Light) == 48
-    assert C.sizeof(abi.Hit) == 48
-    assert C.sizeof(abi.RenderParams) == 48
+def test_struct_sizes_match_header(tmp_path):
+    """The ctypes mirrors in raytracer_amd/abi.py against sizeof() of the C header, compiled here."""
+    import subprocess
+    pairs = {"rt_node": abi.Node, "rt_bvh_node": abi.BvhNode, "rt_material": abi.Material, "rt_light": abi.Light,
+             "rt_hit": abi.Hit, "rt_hit_brief": abi.HitBrief, "rt_render_params": abi.RenderParams, "rt_camera": abi.Camera,
+             "rt_frame_out": abi.FrameOut, "rt_counters": abi.Counters, "rt_photon_params": abi.PhotonParams,
+             "rt_scene_desc": abi.SceneDesc}
+    src = "#include <stdio.h>\n#include \"rt_mi355x.h\"\nint main(void){\n"
+    src += "".join(f'printf("{n} %zu\\n", sizeof({n}));\n' for n in pairs)
+    src += 'printf("rt_photon %zu\\n", sizeof(rt_photon)); return 0; }\n'
+    (tmp_path / "s.c").write_text(src)
+    subprocess.run(["gcc", "-I", os.path.join(O.ROOT, "include"), str(tmp_path / "s.c"), "-o", str(tmp_path / "s")], check=True)
+    out = dict(l.split() for l in subprocess.run([str(tmp_path / "s")], check=True, capture_output=True, text=True).stdout.splitlines())
+    for n, t in pairs.items():
+        assert C.sizeof(t) == int(out[n]), n
+    assert abi.PHOTON_DTYPE.itemsize == int(out["rt_photon"]) == 32
+    assert C.sizeof(abi.Node) == 112 and C.sizeof(abi.BvhNode) == 28
 
 
 def nodes_of(desc):
