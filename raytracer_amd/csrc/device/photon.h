@@ -320,16 +320,27 @@ __global__ __launch_bounds__(kBlock) void k_scan_add(uint32_t *__restrict__ out,
 constexpr int kGatherK = RT_GATHER_MAX_PHOTONS;
 constexpr uint32_t kFarIsLow = 0x80000000u, kFarDone = 0x40000000u;
 
+// Heap of one lane: 130 entries of (dist2, node), entry e at heap[e]; entry 0 is unused (dist2[0] lives in a
+// register), entry 129 is padding so that the pair (j, j+1) can always be read with one 16-byte load.
+// A lane's entries are contiguous in global memory (not interleaved with other lanes' as private arrays
+// are): a sift step is one 16-byte load of both children and one 8-byte store, and the top of the heap,
+// which every replacement goes through, stays on one cache line.
+constexpr uint32_t kHeapStride = 130;
+RT_DEV u32x2 *lane_heap(const DScene &S) { return (u32x2 *)S.gather_heaps + ((size_t)blockIdx.x * kBlock + threadIdx.x) * kHeapStride; }
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
 template <bool COUNT>
-RT_DEV V3 photon_irradiance(const rt_photon *tree0, uint32_t n, V3 pos, V3 normal, float radius, LaneStack st, uint32_t &visits)
+RT_DEV V3 photon_irradiance(const rt_photon *tree0, uint32_t n, V3 pos, V3 normal, float radius, LaneStack st,
+                            u32x2 *heap, uint32_t &visits)
 {
     if (n == 0) return mk(0, 0, 0);
     const GF4 tree = (GF4)(const void *)tree0 - 2; // node i = tree[2 i], tree[2 i + 1]
     const int half = (int)n / 2 - 1;               // nodes below this index are treated as internal (src/photonmap.h:197,346)
-    float d2[kGatherK + 1];
-    uint32_t id[kGatherK + 1];
+    typedef RT_GLOBAL_AS u32x2 *GH2;
+    typedef RT_GLOBAL_AS u32x4 *GH4;
+    const GH2 H = (GH2)heap;
     int found = 0;
-    d2[0] = radius * radius;
+    float lim = radius * radius; // dist2[0]
     int sp = 0;
     uint32_t cur = 1;
     for (;;) {
@@ -353,61 +364,63 @@ RT_DEV V3 photon_irradiance(const rt_photon *tree0, uint32_t n, V3 pos, V3 norma
                 const f4 q0 = tree[2 * node], q1 = tree[2 * node + 1];
                 const V3 dif = mk(q0.x, q0.y, q0.z) - pos;
                 const float dist2 = len2(dif);
-                if (dist2 < d2[0] && !(dot(mk(q1.x, q1.y, q1.z), normal) >= 0.0f)) {
+                if (dist2 < lim && !(dot(mk(q1.x, q1.y, q1.z), normal) >= 0.0f)) {
                     if (found < kGatherK) {
                         ++found;
-                        d2[found] = dist2;
-                        id[found] = node;
+                        H[found] = u32x2{__float_as_uint(dist2), node};
                         if (found == kGatherK) { // build the max-heap
                             const int half_found = found >> 1;
                             for (int k = half_found; k >= 1; --k) {
                                 int parent = k;
-                                const uint32_t tp = id[k];
-                                const float td2 = d2[k];
+                                const u32x2 t = H[k];
+                                const float td2 = __uint_as_float(t.x);
                                 while (parent <= half_found) {
                                     int j = parent + parent;
-                                    if (j < found && d2[j] < d2[j + 1]) ++j;
-                                    if (td2 >= d2[j]) break;
-                                    d2[parent] = d2[j];
-                                    id[parent] = id[j];
+                                    const u32x4 c = *(GH4)&H[j];
+                                    float dj = __uint_as_float(c.x);
+                                    uint32_t ij = c.y;
+                                    if (j < found && dj < __uint_as_float(c.z)) { ++j; dj = __uint_as_float(c.z); ij = c.w; }
+                                    if (td2 >= dj) break;
+                                    H[parent] = u32x2{__float_as_uint(dj), ij};
                                     parent = j;
                                 }
-                                id[parent] = tp;
-                                d2[parent] = td2;
+                                H[parent] = t;
                             }
                         }
                     } else { // replace the farthest
                         int parent = 1, j = 2;
+                        float top = dist2; // what ends up in entry 1
                         while (j <= found) {
-                            if (j < found && d2[j] < d2[j + 1]) ++j;
-                            if (dist2 > d2[j]) break;
-                            d2[parent] = d2[j];
-                            id[parent] = id[j];
+                            const u32x4 c = *(GH4)&H[j];
+                            float dj = __uint_as_float(c.x);
+                            uint32_t ij = c.y;
+                            if (j < found && dj < __uint_as_float(c.z)) { ++j; dj = __uint_as_float(c.z); ij = c.w; }
+                            if (dist2 > dj) break;
+                            H[parent] = u32x2{__float_as_uint(dj), ij};
+                            if (parent == 1) top = dj;
                             parent = j;
                             j <<= 1;
                         }
-                        id[parent] = node;
-                        d2[parent] = dist2;
-                        d2[0] = d2[1];
+                        H[parent] = u32x2{__float_as_uint(dist2), node};
+                        lim = top;
                     }
                 }
             }
             // back up: the parent's far child if it can still hold something closer, else the parent's own photon
             bool up = false;
-            while (sp > 0) {
+            if (sp > 0) {
                 uint32_t data; float plane2;
                 st.pop(sp - 1, data, plane2);
                 const uint32_t parent = data & 0x3FFFFFFFu;
-                if (!(data & kFarDone) && plane2 < d2[0]) {
+                if (!(data & kFarDone) && plane2 < lim) {
                     st.push(sp - 1, data | kFarDone, plane2);
                     cur = (data & kFarIsLow) ? 2 * parent : 2 * parent + 1;
                     descend = true;
-                    break;
+                } else {
+                    --sp;
+                    node = parent;
+                    up = true;
                 }
-                --sp;
-                node = parent;
-                up = true;
-                break;
             }
             if (descend || !up) break;
         }
@@ -415,13 +428,14 @@ RT_DEV V3 photon_irradiance(const rt_photon *tree0, uint32_t n, V3 pos, V3 norma
     }
     V3 sum = mk(0, 0, 0);
     for (int i = 1; i <= found; ++i) {
-        const f4 q0 = tree[2 * id[i]], q1 = tree[2 * id[i] + 1];
+        const uint32_t id = H[i].y;
+        const f4 q0 = tree[2 * id], q1 = tree[2 * id + 1];
         const uint32_t rgb = __float_as_uint(q1.w);
         const V3 col = mk((float)(rgb & 255u) / 255.0f, (float)((rgb >> 8) & 255u) / 255.0f, (float)((rgb >> 16) & 255u) / 255.0f);
         sum = sum + col * q0.w; // Color24::ToColor() * power, constant filter
     }
     if (found > 0) {
-        const float area = kPi * d2[0];
+        const float area = kPi * lim;
         if (area > 0.0f) sum = sum * (1.0f / area);
     }
     return sum;
@@ -434,8 +448,9 @@ __global__ __launch_bounds__(kBlock) void k_photon_irradiance(DScene S, const rt
     extern __shared__ uint32_t lds[];
     const LaneStack st = lane_stack(lds, S);
     uint32_t visits = 0, gathers = 0;
+    u32x2 *heap = lane_heap(S);
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-        const V3 e = photon_irradiance<true>(tree, n_photons, ld3(pos3 + (size_t)i * 3), ld3(nrm3 + (size_t)i * 3), radius, st, visits);
+        const V3 e = photon_irradiance<true>(tree, n_photons, ld3(pos3 + (size_t)i * 3), ld3(nrm3 + (size_t)i * 3), radius, st, heap, visits);
         out3[(size_t)i * 3] = e.x; out3[(size_t)i * 3 + 1] = e.y; out3[(size_t)i * 3 + 2] = e.z;
         ++gathers;
     }

@@ -55,6 +55,7 @@ struct DScene {
     uint2 *stack_overflow; // [(stack_levels - lds_levels)][threads of the largest grid]
     const rt_photon *pmap[2]; // balanced photon maps (global, caustics), node 1 first; null when not built
     uint32_t pmap_n[2];
+    uint2 *gather_heaps; // [threads of the largest grid][130]: the lanes' heaps of nearest photons
 };
 
 // Frame constants (camera + sampling), by value in the kernel arguments.

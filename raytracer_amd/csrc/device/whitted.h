@@ -18,10 +18,14 @@
 
 namespace rtd {
 
+#ifndef RT_GATHER_QUORUM
+#define RT_GATHER_QUORUM 32
+#endif
+constexpr int kGatherQuorum = RT_GATHER_QUORUM; // parked lanes that start a round of photon lookups
 constexpr int kMaxWhittedBounces = 8; // the snapshot compiles in 5; the tree grows as 3^bounces
 
-enum { W_IDLE = 0, W_TRACE = 1, W_SHADOW = 2, W_CTRL = 3, W_RET = 4 };
-enum { STG_LIGHT = 0, STG_AFTER = 1, STG_MC = 2, STG_REFL = 3, STG_REFR = 4, STG_TRANS = 5 };
+enum { W_IDLE = 0, W_TRACE = 1, W_SHADOW = 2, W_CTRL = 3, W_RET = 4, W_GATHER = 5 };
+enum { STG_LIGHT = 0, STG_AFTER = 1, STG_BOUNCE = 6, STG_MC = 2, STG_REFL = 3, STG_REFR = 4, STG_TRANS = 5 };
 enum { COMB_MC = 0, COMB_REFL = 1, COMB_TIR = 2, COMB_FRESNEL = 3, COMB_TRANS = 4 };
 
 // One level of the Shade recursion: what Shade still needs after a child ray has returned.
@@ -148,6 +152,26 @@ __global__ __launch_bounds__(kBlock, 4) void k_whitted(DScene S, DFrame F, const
         if (!__any(state != W_IDLE)) {
             if (wq.exhausted) break;
             continue;
+        }
+
+        // Photon lookups are long (hundreds of kd-tree nodes) next to a ray of this kind of scene, and lanes reach
+        // them at different times: parked lanes wait until half the wave is parked or nothing else is left to do,
+        // then gather together.
+        const uint64_t parked = __ballot(state == W_GATHER);
+        if (parked != 0 && (__popcll(parked) >= kGatherQuorum || !__any(state == W_TRACE || state == W_SHADOW))) {
+            if (state == W_GATHER) {
+                const V3 kd = ld3(S.materials[mtl].diffuse) * kInvPiF;
+                u32x2 *heap = lane_heap(S);
+                if (pm & (RT_PM_DIRECT | RT_PM_INDIRECT)) {
+                    cur.final = cur.final + kd * photon_irradiance<COUNT>(S.pmap[0], S.pmap_n[0], cur.p, cur.n, F.gather_radius, st, heap, visits);
+                    ++gathers;
+                }
+                if (pm & RT_PM_CAUSTICS) {
+                    cur.final = cur.final + kd * photon_irradiance<COUNT>(S.pmap[1], S.pmap_n[1], cur.p, cur.n, F.gather_radius, st, heap, visits);
+                    ++gathers;
+                }
+                state = W_CTRL;
+            }
         }
 
         if (state == W_TRACE) { // camera ray (depth 0) or TraceSecondaryRay
@@ -277,19 +301,13 @@ __global__ __launch_bounds__(kBlock, 4) void k_whitted(DScene S, DFrame F, const
                 break;
             }
             if (stage == STG_AFTER) {
-                // irradiance from the photon maps (p12 materials.cpp:49-70).  The reference also runs the estimate for a
-                // specular surface that is no photon surface and drops the result; that lookup is skipped here.
-                if (pm != 0 && is_photon_surface(m)) {
-                    const V3 kd = ld3(m.diffuse) * kInvPiF;
-                    if (pm & (RT_PM_DIRECT | RT_PM_INDIRECT)) {
-                        cur.final = cur.final + kd * photon_irradiance<COUNT>(S.pmap[0], S.pmap_n[0], cur.p, cur.n, F.gather_radius, st, visits);
-                        ++gathers;
-                    }
-                    if (pm & RT_PM_CAUSTICS) {
-                        cur.final = cur.final + kd * photon_irradiance<COUNT>(S.pmap[1], S.pmap_n[1], cur.p, cur.n, F.gather_radius, st, visits);
-                        ++gathers;
-                    }
-                }
+                // irradiance from the photon maps (p12 materials.cpp:49-70): the lane parks until the wave gathers.
+                // The reference also runs the estimate for a specular surface that is no photon surface and drops
+                // the result; that lookup is skipped.
+                stage = STG_BOUNCE;
+                if (pm != 0 && is_photon_surface(m)) { state = W_GATHER; break; }
+            }
+            if (stage == STG_BOUNCE) {
                 if (!(depth < F.max_bounces)) { ret = cur.final; retDist = cur.dist; state = W_RET; continue; } // CanBounce
                 stage = STG_MC;
             }

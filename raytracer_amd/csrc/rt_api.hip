@@ -77,7 +77,7 @@ struct rt_ctx {
     DeviceBuf d_rgb, d_z, d_cnt, d_id, d_lin; // internal planes when the caller wants host output
     DeviceBuf d_q_in, d_q_aux, d_q_out;       // batch queries
     // photon maps: balanced trees the shader reads, and scratch of the emission launches
-    DeviceBuf d_pmap[2], d_ph_raw, d_ph_counts, d_ph_offsets, d_ph_tiles, d_ph_total;
+    DeviceBuf d_gather_heaps, d_pmap[2], d_ph_raw, d_ph_counts, d_ph_offsets, d_ph_tiles, d_ph_total;
     uint32_t pmap_n[2] = {0, 0};
     int pmap_flags = -1; // RT_PM_* bits the maps were filled with, -1 = not known (built from caller's photons)
     std::vector<int32_t> active_host;
@@ -923,6 +923,14 @@ int ensure_stack_levels(rt_ctx *ctx, int levels)
     return RT_OK;
 }
 
+// one heap of nearest photons per thread of the largest grid (545 MB on 256 CUs), allocated with the first map
+int ensure_gather_heaps(rt_ctx *ctx)
+{
+    HIP_TRY(ctx, ctx->d_gather_heaps.reserve(ctx->ovf_threads * kHeapStride * sizeof(uint2)));
+    ctx->scene.gather_heaps = ctx->d_gather_heaps.as<uint2>();
+    return RT_OK;
+}
+
 int validate_photon_params(rt_ctx *ctx, const rt_photon_params *p, int which)
 {
     if (!p) return ctx->fail(RT_ERR_INVALID, "null photon params");
@@ -1057,6 +1065,7 @@ int rt_photons_build(rt_ctx *ctx, int which, const rt_photon *photons, uint32_t 
     int levels = 1;
     while ((1u << levels) <= n) ++levels; // tree height
     if (int rc = ensure_stack_levels(ctx, levels + 1)) return rc;
+    if (int rc = ensure_gather_heaps(ctx)) return rc;
     ctx->pmap_n[which] = n;
     return RT_OK;
 }
