@@ -24,7 +24,7 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 from raytracer_amd import abi, lib, scenes  # noqa: E402
-from raytracer_amd.dist import FrameBuffers, FrameGather  # noqa: E402
+from raytracer_amd.dist import FrameBuffers, FrameGather, PhotonFill  # noqa: E402
 
 # algorithmic flop constants, hand-counted from the reference code (+,-,*,/,min,max,
 # compare-select, sqrt = 1): ray into node space 33, hit back to the parent 48 per level,
@@ -39,27 +39,49 @@ PEAK_HBM_GBPS = 8000.0    # MI355X HBM3E
 B_BOX, B_TRI, B_HIT, B_PIXEL = 28, 52, 96, 15
 
 WORKLOADS = {
-    # name: (mesh quads x, y, width, height, spp)
-    "mesh_1m_1080p_64spp": (1000, 500, 1920, 1080, 64),
-    "mesh_64k_540p_8spp": (250, 128, 960, 540, 8),  # development size
+    # path tracer on a triangle mesh: (mesh quads x, y, width, height, spp)
+    "mesh_1m_1080p_64spp": (1000, 500, 1920, 1080, 64),   # the headline configuration
+    "mesh_64k_540p_8spp": (250, 128, 960, 540, 8),        # development size
+    "mesh_10m_4k_adaptive": (5000, 1000, 3840, 2160, (16, 256)),  # 10M triangles, 4K, 16..256 spp with the variance stop
+    # Whitted-style shader (project-12 snapshot): Blinn-Phong + adaptive soft shadows, no recursion
+    "spheres_1080p_16spp_whitted": ("spheres", 8, 1920, 1080, 16),
+    # photon maps: 10M + 1M photons traced, balanced and gathered from, 16..64 spp adaptive, 5 bounces
+    "photon_box_1080p": ("photons", (10_000_000, 1_000_000), 1920, 1080, (16, 64)),
+    "photon_box_540p_small": ("photons", (1_000_000, 100_000), 960, 540, (16, 64)),  # development size
 }
+B_PHOTON = 32  # a kd-tree node visit reads one 32-byte photon record; a stored photon writes one
 
 
 def build_scene(name):
-    nx, ny, w, h, spp = WORKLOADS[name]
-    mesh = scenes.heightfield(nx, ny)
+    """-> host scene, width, height, (min spp, max spp), triangles, mode, max_bounces, photon params or None"""
+    kind, arg, w, h, spp = WORKLOADS[name]
+    spp = spp if isinstance(spp, tuple) else (spp, spp)
+    if kind == "spheres":
+        return lib.HostScene.from_string(scenes.spheres_scene_xml(grid=arg, width=w, height=h)), w, h, spp, 0, abi.RT_MODE_WHITTED, 0, None
+    if kind == "photons":
+        # the reference's own scene (its Cornell box with mirror, glass and glossy spheres), held as a flattened fixture
+        hs = abi.scene_from_fixture(dict(np.load(os.path.join(ROOT, "tests", "golden", "scene_a.npz"))))
+        hs.camera.width, hs.camera.height = w, h
+        pp = abi.PhotonParams(flags=abi.RT_PM_INDIRECT | abi.RT_PM_CAUSTICS, n_global=arg[0], n_caustic=arg[1], max_segments=64, seed=7)
+        return hs, w, h, spp, 0, abi.RT_MODE_WHITTED, 5, pp
+    mesh = scenes.heightfield(kind, arg)
     hs = lib.HostScene.from_string(scenes.mesh_scene_xml("mesh.obj", w, h))
     hs.set_mesh("mesh.obj", mesh["v"], mesh["vt"], mesh["f"])
-    return hs, w, h, spp, len(mesh["f"])
+    return hs, w, h, spp, len(mesh["f"]), abi.RT_MODE_PATH, 50, None
 
 
-def algorithmic_flops(desc, c):
+def algorithmic_flops(desc, c, mode=abi.RT_MODE_PATH):
     """Flops one frame needs by the reference's own algorithm, from the kernels' ray / visit counters."""
     prims = [desc.nodes[i].prim for i in range(desc.n_nodes)]
     n_nodes, n_sph, n_pl = desc.n_nodes, prims.count(abi.RT_PRIM_SPHERE), prims.count(abi.RT_PRIM_PLANE)
     per_closest = F_NODE * n_nodes + F_SPH * n_sph + F_PLANE * n_pl + F_LIGHT * desc.n_lights
     per_shadow = F_NODE * n_nodes + F_SPH_SH * n_sph + F_PLANE * n_pl
-    vertices = c.shadow_rays  # every shaded surface vertex sends exactly one shadow ray
+    # path tracer: every shaded surface vertex sends exactly one shadow ray; Whitted-style shader: a vertex is a
+    # closest hit on a surface (about as many as closest rays) and its shading is ~120 flops + ~60 per fan ray
+    if mode == abi.RT_MODE_WHITTED:
+        return (c.closest_rays * (per_closest + 2 * F_BACK + 120) + c.shadow_rays * (per_shadow + 60)
+                + F_BOX * c.box_tests + F_TRI * c.tri_tests + 20 * c.photon_visits)
+    vertices = c.shadow_rays
     return (c.closest_rays * per_closest + c.shadow_rays * per_shadow + F_BOX * c.box_tests + F_TRI * c.tri_tests
             + vertices * (2 * F_BACK + F_SHADE))
 
@@ -81,7 +103,7 @@ def measured_traffic(workload):
     return None, None
 
 
-def cpu_baseline(hs, w, h, spp, budget_s=12.0):
+def cpu_baseline(hs, w, h, prm_gpu, pp, budget_s=12.0):
     """The CPU restatement of the reference (test oracle), timed on this host's cores on a bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import ctypes as C
@@ -89,7 +111,17 @@ def cpu_baseline(hs, w, h, spp, budget_s=12.0):
     cores = int(os.environ.get("OMP_NUM_THREADS", 0)) or min(16, os.cpu_count() or 1)
     L = O.lib(fast=True)
     cam = abi.Camera.from_buffer_copy(hs.camera)
-    prm = abi.default_params(min_spp=spp, max_spp=spp, seed=7)
+    prm = abi.RenderParams.from_buffer_copy(prm_gpu)
+    prm.tile_rank, prm.tile_world = 0, 1
+    note = ""
+    if pp:
+        # the serial emission loop and the kd-tree build of 10M photons take minutes on the CPU: the baseline frame
+        # uses maps of a tenth of the size (the gather cost per lookup is nearly independent of the map size)
+        small = abi.PhotonParams.from_buffer_copy(pp)
+        small.n_global, small.n_caustic = max(1, pp.n_global // 10), max(1, pp.n_caustic // 10)
+        t0 = time.perf_counter()
+        O.fill_photon_maps(hs, small)
+        note = f"; photon maps of {small.n_global}+{small.n_caustic} photons filled and balanced single-threaded in {time.perf_counter() - t0:.1f} s (not in the rate)"
     fr = O.Frame(w, h)
     band = 16
     order = np.random.RandomState(0).permutation(h // band)
@@ -104,7 +136,8 @@ def cpu_baseline(hs, w, h, spp, budget_s=12.0):
             break
     dt = time.perf_counter() - t0
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": f"{bands} random {band}-row bands of the same {w}x{h} frame at {spp} spp ({rays} rays in {dt:.1f} s)"}
+            "sample": f"{bands} random {band}-row bands of the same {w}x{h} frame at {prm.min_spp}..{prm.max_spp} spp "
+                      f"({rays} rays in {dt:.1f} s){note}"}
 
 
 def main():
@@ -114,7 +147,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="mesh_1m_1080p_64spp", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--max-bounces", type=int, default=50, help="development only: the headline number uses 50")
+    ap.add_argument("--max-bounces", type=int, default=None, help="development only: the headline number uses 50")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -127,17 +160,24 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
 
-    hs, w, h, spp, ntri = build_scene(args.workload)
+    hs, w, h, (spp_min, spp_max), ntri, mode, bounces, pp = build_scene(args.workload)
+    if args.max_bounces is not None:
+        bounces = args.max_bounces
+    headline = args.workload == "mesh_1m_1080p_64spp" and bounces == 50
     ctx = lib.Context(local)
     ctx.upload(hs.desc)
     ctx.set_camera(hs.camera)
-    prm = abi.default_params(min_spp=spp, max_spp=spp, seed=7, tile_rank=rank, tile_world=world,
-                             max_bounces=args.max_bounces)
+    prm = abi.default_params(mode=mode, min_spp=spp_min, max_spp=spp_max, seed=7, tile_rank=rank, tile_world=world,
+                             max_bounces=bounces, photon_flags=pp.flags if pp else 0, gather_radius=3.0)
     fb = FrameBuffers(w, h, dev)
     gather = FrameGather(w, h, prm.tile_size, rank, world, dev)
+    filler = PhotonFill(ctx, rank, world, dev) if pp else None
     host_rgb = torch.empty((w * h, 3), dtype=torch.uint8).pin_memory()
+    photon_stats = {}
 
     def step():
+        if filler:  # the maps are part of the frame: emitted by all ranks, gathered, balanced on every rank
+            photon_stats.update(filler(pp))
         ctx.render_device(prm, rgb=fb.rgb.data_ptr(), z=fb.z.data_ptr(), sample_count=fb.sample_count.data_ptr(),
                           object_id=fb.object_id.data_ptr())
         gather(fb)
@@ -168,23 +208,33 @@ def main():
     dt = time.perf_counter() - t0
 
     c = ctx.counters()
-    stats = torch.tensor([c.closest_rays, c.shadow_rays, c.camera_paths, counted.box_tests, counted.tri_tests],
-                         dtype=torch.float64, device=dev)
+    photon_rays = photon_stats.get("rays", 0)
+    stats = torch.tensor([c.closest_rays, c.shadow_rays, c.camera_paths, counted.box_tests, counted.tri_tests,
+                          c.gathers, counted.photon_visits, photon_rays], dtype=torch.float64, device=dev)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(stats)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
-    rays_per_frame = float(stats[0] + stats[1])
+    rays_per_frame = float(stats[0] + stats[1] + stats[7])
 
     if rank == 0:
         n_launch = max(1, counted.trace_launches)
-        flops_launch = algorithmic_flops(hs.desc, counted) / n_launch
-        bytes_launch = algorithmic_bytes(counted, w * h // world) / n_launch
+        kernel = {abi.RT_MODE_PATH: "k_paths", abi.RT_MODE_WHITTED: "k_whitted"}[mode]
+        flops_launch = algorithmic_flops(hs.desc, counted, mode) / n_launch
+        bytes_launch = (algorithmic_bytes(counted, w * h // world) + B_PHOTON * counted.photon_visits) / n_launch
         avg_launch_s = kernel_ms / max(1, launches) / 1e3
         tflops = flops_launch / avg_launch_s / 1e12
         gbps = bytes_launch / avg_launch_s / 1e9
-        traffic, traffic_src = measured_traffic(args.workload) if world == 1 and args.max_bounces == 50 else (None, None)
+        traffic, traffic_src = measured_traffic(args.workload) if world == 1 and headline else (None, None)
+        valu = {"achieved": tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": tflops / PEAK_FP32_TFLOPS,
+                "algorithmic_gflop_per_launch": flops_launch / 1e9}
+        hbm = {"achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
+               "algorithmic_gbyte_per_launch": bytes_launch / 1e9}
+        # the BVH walk and the photon gather are dependent fetches: memory bounds them; a scene of spheres and planes
+        # (every ray tests every node, the node list sits in the scalar cache) is bounded by FP32 VALU work
+        mem_bound = ntri > 0 or pp is not None
+        first, second, second_key = (hbm, valu, "valu_fp32") if mem_bound else (valu, hbm, "hbm")
         out = {
             "metric": "Mrays/sec (whole node) at 1/2/4/8 MI355X, 1M-tri 1080p",
             "value": rays_per_frame * args.steps / dt / 1e6,
@@ -196,23 +246,26 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": args.workload, "triangles": ntri, "width": w, "height": h, "spp": spp,
-                       "max_bounces": prm.max_bounces, "mode": "path", "parallelism": f"tiles/{world}",
-                       "rays_per_frame": int(rays_per_frame), "camera_paths_per_frame": int(stats[2].item())},
-            # the BVH walk is a dependent gather: memory is the roofline that bounds it; the FP32 side is reported beside it
-            "roofline": {"bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                         "frac": gbps / PEAK_HBM_GBPS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "k_paths", "avg_launch_ms": avg_launch_s * 1e3,
-                         "algorithmic_gbyte_per_launch": bytes_launch / 1e9,
-                         "valu_fp32": {"achieved": tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                                       "frac": tflops / PEAK_FP32_TFLOPS, "algorithmic_gflop_per_launch": flops_launch / 1e9},
-                         "box_tests_per_frame": int(stats[3].item()), "tri_tests_per_frame": int(stats[4].item()),
-                         "note": "rank 0's launch; algorithmic bytes and flops from the kernels' own ray/box/triangle counters"},
+            "config": {"workload": args.workload, "triangles": ntri, "width": w, "height": h, "spp": [spp_min, spp_max],
+                       "max_bounces": prm.max_bounces, "mode": "path" if mode == abi.RT_MODE_PATH else "whitted",
+                       "parallelism": f"tiles/{world}", "rays_per_frame": int(rays_per_frame),
+                       "camera_paths_per_frame": int(stats[2].item())},
+            "roofline": dict(first, bound="hbm" if mem_bound else "valu_fp32", traffic=traffic, traffic_source=traffic_src,
+                             kernel=kernel, avg_launch_ms=avg_launch_s * 1e3, launches_per_frame=n_launch,
+                             box_tests_per_frame=int(stats[3].item()), tri_tests_per_frame=int(stats[4].item()),
+                             note="rank 0's launches; algorithmic bytes and flops from the kernels' own ray/box/triangle/photon counters",
+                             **{second_key: second}),
         }
+        if pp:
+            out["photons"] = {"global": pp.n_global, "caustics": pp.n_caustic, "paths": photon_stats.get("paths"),
+                              "photon_rays_per_frame": int(stats[7].item()), "emit_ms": photon_stats.get("emit_ms"),
+                              "gather_ms": photon_stats.get("gather_ms"), "build_ms": photon_stats.get("build_ms"),
+                              "gathers_per_frame": int(stats[5].item()), "node_visits_per_frame": int(stats[6].item()),
+                              "gathers_per_s": float(stats[5].item()) * args.steps / dt}
         if any(c.phase_cycles):
             out["phase_cycles"] = list(c.phase_cycles)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(hs, w, h, spp)
+            out["cpu_baseline"] = cpu_baseline(hs, w, h, prm, pp)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -214,3 +214,16 @@ def bvh_depth(words):
             c = data & 0x7FFFFFFF
             stack += [(c, d + 1), (c + 1, d + 1)]
     return depth
+
+
+def scene_from_fixture(g):
+    """SceneArrays from the `scene_*` arrays of a fixture file (a flattened scene dump: node transforms, parents,
+    primitives, materials, lights, camera, meshes with their BVHs)."""
+    meshes = []
+    k = 0
+    while f"scene_mesh{k}_v" in g:
+        meshes.append({n: g[f"scene_mesh{k}_{n}"] for n in ("v", "vn", "vt", "f", "fn", "ft", "bvh_nodes", "bvh_elements")})
+        k += 1
+    return scene_from_arrays(g["scene_node_tm"], g["scene_node_itm"], g["scene_node_parent"], g["scene_node_prim"],
+                             g["scene_node_mesh"], g["scene_node_material"], g["scene_materials"], g["scene_lights"],
+                             background=g["scene_background"], meshes=meshes, camera=g["scene_camera"])

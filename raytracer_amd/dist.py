@@ -75,3 +75,89 @@ class FrameGather:
             fb.sample_count[idx] = blk[:, 7:11].contiguous().view(torch.int32).reshape(m)
             fb.object_id[idx] = blk[:, 11:15].contiguous().view(torch.int32).reshape(m)
         return fb
+
+
+class PhotonFill:
+    """Fills the photon maps with every rank tracing a share of the photon paths.
+
+    The reference fills a map with one serial loop: photon paths run one after the other until the map is
+    full (project12.zip src/main.cpp:292-470).  With one random stream per path the photons a path stores
+    do not depend on who traces it, so a round of paths is cut into `world` contiguous blocks, rank r
+    traces block r, and the blocks' photons - concatenated in rank order, which is path order - are what
+    the serial loop would have stored.  Per round: one all_gather of the ranks' photon counts and one of
+    their 32-byte records (padded to the largest count); no other exchange.  Every rank ends up with the
+    whole list, cuts it at the map's capacity and balances its own copy of the kd-tree.
+
+    `emit(pp, which, path_begin, path_count, capacity) -> (uint8 tensor [m, 32] on `device`, stored)` and
+    `build(which, uint8 tensor [n, 32])` default to the GPU library; tests pass CPU stand-ins.
+    """
+
+    FIRST_ROUND = 1 << 16
+
+    def __init__(self, ctx, rank, world, device, emit=None, build=None):
+        self.ctx, self.rank, self.world, self.device = ctx, rank, world, device
+        self.emit = emit or self._emit_gpu
+        self.build = build or self._build_gpu
+        self._scratch = None
+
+    def _emit_gpu(self, pp, which, path_begin, path_count, capacity):
+        if self._scratch is None or self._scratch.shape[0] < capacity:
+            self._scratch = torch.empty((max(1, capacity), 32), dtype=torch.uint8, device=self.device)
+        _, stored = self.ctx.photons_emit(pp, which, path_begin, path_count, capacity, device_ptr=self._scratch.data_ptr())
+        c = self.ctx.counters()
+        self.stats["rays"] += int(c.closest_rays)
+        self.stats["emit_ms"] += float(c.kernel_ms)
+        return self._scratch[:min(stored, capacity)], stored
+
+    def _build_gpu(self, which, records):
+        torch.cuda.synchronize(self.device)
+        self.ctx.photons_build(which, device_ptr=records.data_ptr(), n=records.shape[0])
+
+    def __call__(self, pp):
+        import time
+        self.stats = {"rays": 0, "paths": 0, "emit_ms": 0.0, "gather_ms": 0.0, "build_ms": 0.0}
+        world, rank = self.world, self.rank
+        for which in (0, 1):
+            cap = pp.n_caustic if which == 1 else pp.n_global
+            enabled = (pp.flags & 4) if which == 1 else (pp.flags & (1 | 2 | 8))
+            if not enabled or cap == 0:
+                self.build(which, torch.empty((0, 32), dtype=torch.uint8, device=self.device))
+                continue
+            buf = torch.empty((cap, 32), dtype=torch.uint8, device=self.device)
+            stored, path, rnd, barren = 0, 0, self.FIRST_ROUND, 0
+            while stored < cap:
+                block = -(-rnd // world)
+                mine, n_mine = self.emit(pp, which, path + rank * block, block, cap - stored)
+                n_mine = min(int(n_mine), cap - stored)
+                t0 = time.perf_counter()
+                if world > 1:
+                    counts = torch.zeros(world, dtype=torch.int64, device=self.device)
+                    me = torch.tensor([n_mine], dtype=torch.int64, device=self.device)
+                    dist.all_gather_into_tensor(counts, me)
+                    counts = counts.tolist()
+                    most = max(1, max(counts))
+                    send = torch.zeros((most, 32), dtype=torch.uint8, device=self.device)
+                    send[:n_mine] = mine[:n_mine]
+                    recv = torch.empty((world, most, 32), dtype=torch.uint8, device=self.device)
+                    dist.all_gather_into_tensor(recv.view(-1), send.view(-1))
+                    parts = [recv[r, :counts[r]] for r in range(world)]
+                else:
+                    counts, parts = [n_mine], [mine[:n_mine]]
+                for part in parts:  # rank order = path order
+                    take = min(part.shape[0], cap - stored)
+                    buf[stored:stored + take] = part[:take]
+                    stored += take
+                self.stats["gather_ms"] += (time.perf_counter() - t0) * 1e3
+                path += block * world
+                got = sum(counts)
+                # the next round asks for what is still missing at the yield seen so far, plus a little
+                yield_ = max(stored, 1) / path
+                rnd = int(min(1 << 24, max(self.FIRST_ROUND, 1.05 * (cap - stored) / yield_ + 1024)))
+                barren = barren + 1 if got == 0 else 0
+                if barren >= 8 and stored == 0:
+                    raise RuntimeError(f"no photon stored after {path} paths: the scene has no surface that takes photons for this map")
+            self.stats["paths"] += path
+            t0 = time.perf_counter()
+            self.build(which, buf)
+            self.stats["build_ms"] += (time.perf_counter() - t0) * 1e3
+        return self.stats

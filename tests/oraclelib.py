@@ -88,14 +88,7 @@ def load_golden(name):
 
 def scene_from_golden(g):
     """Build abi.SceneArrays from the `scene_*` arrays of a golden fixture (the reference's own scene dump)."""
-    meshes = []
-    k = 0
-    while f"scene_mesh{k}_v" in g:
-        meshes.append({n: g[f"scene_mesh{k}_{n}"] for n in ("v", "vn", "vt", "f", "fn", "ft", "bvh_nodes", "bvh_elements")})
-        k += 1
-    return abi.scene_from_arrays(g["scene_node_tm"], g["scene_node_itm"], g["scene_node_parent"], g["scene_node_prim"],
-                                 g["scene_node_mesh"], g["scene_node_material"], g["scene_materials"], g["scene_lights"],
-                                 background=g["scene_background"], meshes=meshes, camera=g["scene_camera"])
+    return abi.scene_from_fixture(g)
 
 
 class Frame:

@@ -78,3 +78,49 @@ def test_shards_partition_the_frame():
         tiles = -(-w // tile) * -(-h // tile)
         if tiles >= world * 8:  # fine interleaving keeps the shards within a few tiles of each other
             assert max(sizes) - min(sizes) <= 2 * tile * tile
+
+
+def _photon_worker(rank, world, port, out_dir):
+    """PhotonFill with the oracle standing in for the GPU emission kernel and the host kd-tree build."""
+    import oraclelib as O
+    from raytracer_amd import abi
+    from raytracer_amd.dist import PhotonFill
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        s = O.scene_from_golden(O.load_golden("scene_a"))
+        pp = abi.PhotonParams(flags=abi.RT_PM_INDIRECT | abi.RT_PM_CAUSTICS, n_global=3000, n_caustic=700, max_segments=64, seed=5)
+        trees = {}
+
+        def emit(pp_, which, path_begin, path_count, capacity):
+            # all photons these paths store (the caller cuts at its capacity), as the GPU entry point reports them
+            got, _ = O.photons_emit(s, pp_, which, path_begin, path_count, capacity=1 << 20)
+            return torch.from_numpy(got[:capacity].view(np.uint8).reshape(-1, 32).copy()), len(got)
+
+        def build(which, records):
+            trees[which] = O.photon_build(records.numpy().reshape(-1).view(abi.PHOTON_DTYPE))
+
+        fill = PhotonFill(None, rank, world, torch.device("cpu"), emit=emit, build=build)
+        fill.FIRST_ROUND = 2048  # several rounds, the last one cut at the capacity
+        stats = fill(pp)
+        assert stats["paths"] > 0
+        np.savez(os.path.join(out_dir, f"photons{rank}.npz"), g=trees[0].view(np.uint8), c=trees[1].view(np.uint8))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_photon_fill_matches_serial_emission(tmp_path, world):
+    """Ranks trace contiguous blocks of photon paths and all-gather the records: every rank must end up with
+    exactly the maps the reference's serial loop gives (same photons, same order, same kd-tree)."""
+    import oraclelib as O
+    from raytracer_amd import abi
+    mp.spawn(_photon_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    s = O.scene_from_golden(O.load_golden("scene_a"))
+    pp = abi.PhotonParams(flags=abi.RT_PM_INDIRECT | abi.RT_PM_CAUSTICS, n_global=3000, n_caustic=700, max_segments=64, seed=5)
+    ref = O.fill_photon_maps(s, pp)
+    for rank in range(world):
+        d = np.load(tmp_path / f"photons{rank}.npz")
+        assert np.array_equal(d["g"], ref[0].view(np.uint8)), f"rank {rank}: global map"
+        assert np.array_equal(d["c"], ref[1].view(np.uint8)), f"rank {rank}: caustics map"
