@@ -49,6 +49,7 @@ WORKLOADS = {
     "photon_box_1080p": ("photons", (10_000_000, 1_000_000), 1920, 1080, (16, 64)),
     "photon_box_540p_small": ("photons", (1_000_000, 100_000), 960, 540, (16, 64)),  # development size
 }
+MESHES = {}  # generated meshes by workload, kept for the reference baseline (it reads the OBJ text)
 B_PHOTON = 32  # a kd-tree node visit reads one 32-byte photon record; a stored photon writes one
 
 
@@ -65,6 +66,7 @@ def build_scene(name):
         pp = abi.PhotonParams(flags=abi.RT_PM_INDIRECT | abi.RT_PM_CAUSTICS, n_global=arg[0], n_caustic=arg[1], max_segments=64, seed=7)
         return hs, w, h, spp, 0, abi.RT_MODE_WHITTED, 5, pp
     mesh = scenes.heightfield(kind, arg)
+    MESHES[name] = mesh
     hs = lib.HostScene.from_string(scenes.mesh_scene_xml("mesh.obj", w, h))
     hs.set_mesh("mesh.obj", mesh["v"], mesh["vt"], mesh["f"])
     return hs, w, h, spp, len(mesh["f"]), abi.RT_MODE_PATH, 50, None
@@ -138,6 +140,38 @@ def cpu_baseline(hs, w, h, prm_gpu, pp, budget_s=12.0):
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
             "sample": f"{bands} random {band}-row bands of the same {w}x{h} frame at {prm.min_spp}..{prm.max_spp} spp "
                       f"({rays} rays in {dt:.1f} s){note}"}
+
+
+def cpu_baseline_reference(ctx, mesh, cores, width=960, height=540):
+    """The reference renderer itself (oracle/_ref/ref_harness_time: the reference's sources compiled -O3 in the build
+    container, its own thread pool, its compiled-in 128 spp and 50 bounces) on the same scene at a reduced frame
+    size.  The reference does not count rays; the ray count is the GPU's for the same frame (same scene, camera,
+    spp; path tracing statistics, so the counts agree to well under 1 %).  None if the binary is not there."""
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_harness_time")
+    if not os.path.exists(exe):
+        return None
+    with tempfile.TemporaryDirectory() as tmp:
+        scenes.write_obj(os.path.join(tmp, "mesh.obj"), mesh)
+        xml = scenes.mesh_scene_xml("mesh.obj", width, height)
+        with open(os.path.join(tmp, "scene.xml"), "w") as fp:
+            fp.write(xml)
+        try:
+            r = subprocess.run([exe, "scene.xml", tmp, "time", str(cores)], cwd=tmp, capture_output=True, text=True, timeout=600)
+            ms = json.loads(r.stdout.strip().splitlines()[-1])["ms"]
+        except Exception as e:  # an illegal instruction on an older host CPU, a timeout: fall back to the port
+            print(f"reference baseline not available: {e}", file=sys.stderr)
+            return None
+    hs = lib.HostScene.from_string(xml)
+    hs.set_mesh("mesh.obj", mesh["v"], mesh["vt"], mesh["f"])
+    ctx.set_camera(hs.camera)
+    ctx.render_device(abi.default_params(min_spp=128, max_spp=128, seed=7))
+    c = ctx.counters()
+    rays = c.closest_rays + c.shadow_rays
+    return {"value": rays / ms / 1e3, "unit": "Mrays/s", "cores": cores, "kind": "reference",
+            "sample": f"the reference's own renderer (its thread pool with {cores} threads, 128 spp, 50 bounces) on the same scene at "
+                      f"{width}x{height}: {ms / 1e3:.1f} s for {rays} rays (ray count taken from the GPU's frame of the same size)"}
 
 
 def main():
@@ -265,7 +299,11 @@ def main():
         if any(c.phase_cycles):
             out["phase_cycles"] = list(c.phase_cycles)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(hs, w, h, prm, pp)
+            port = cpu_baseline(hs, w, h, prm, pp)
+            ref = cpu_baseline_reference(ctx, MESHES[args.workload], port["cores"]) if args.workload in MESHES and mode == abi.RT_MODE_PATH and ntri <= 2_000_000 else None
+            out["cpu_baseline"] = ref or port
+            if ref:
+                out["cpu_baseline_port"] = port  # our CPU restatement of the same algorithm (the parity oracle), -O3, same cores
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
