@@ -219,6 +219,41 @@ public:
         if (!ctx || rt_trace_shadow(ctx, ray.p, &t_max, 1, &occluded) != RT_OK) return false;
         return occluded != 0;
     }
+    // ---- photon maps: Renderer::Get/SetPhotonMap, Get/SetCausticsMap (src/renderer.h:221-224) and the emission
+    // loops of the project-12 snapshot's main() (project12.zip src/main.cpp:262-470).  The reference hands the
+    // renderer a PhotonMap it filled itself; here the library fills and owns the maps, FillPhotonMaps replaces
+    // the loops, and GetPhotonMap / GetCausticsMap return a host copy in PhotonMap::GetPhotons() order.
+    bool FillPhotonMaps(rt_photon_params const &pp)
+    {
+        if (!ctx || !host) return Fail("FillPhotonMaps", "no scene loaded");
+        if ((lastStatus = rt_photons_fill(ctx, &pp)) != RT_OK) return Fail("rt_photons_fill", rt_last_error(ctx));
+        params.photon_flags = pp.flags; // the shader reads what was filled
+        return true;
+    }
+    // Renderer::SetPhotonMap with photons the caller traced (emission order, unscaled powers)
+    bool SetPhotonMap(rt_photon const *photons, uint32_t n) { return SetMap(RT_MAP_GLOBAL, photons, n); }
+    bool SetCausticsMap(rt_photon const *photons, uint32_t n) { return SetMap(RT_MAP_CAUSTICS, photons, n); }
+    std::vector<rt_photon> GetPhotonMap() const { return GetMap(RT_MAP_GLOBAL); }
+    std::vector<rt_photon> GetCausticsMap() const { return GetMap(RT_MAP_CAUSTICS); }
+
+private:
+    bool SetMap(int which, rt_photon const *photons, uint32_t n)
+    {
+        if (!ctx) return Fail("SetPhotonMap", "no GPU context");
+        if ((lastStatus = rt_photons_build(ctx, which, photons, n, 0)) != RT_OK) return Fail("rt_photons_build", rt_last_error(ctx));
+        return true;
+    }
+    std::vector<rt_photon> GetMap(int which) const
+    {
+        uint32_t n = 0;
+        std::vector<rt_photon> out;
+        if (!ctx || rt_photons_download(ctx, which, nullptr, &n) != RT_OK || n == 0) return out;
+        out.resize(n);
+        if (rt_photons_download(ctx, which, out.data(), &n) != RT_OK) out.clear();
+        return out;
+    }
+
+public:
     // many rays at once: one launch instead of one per ray
     bool TraceRays(const Ray *rays, int n, rt_hit *hits) const { return ctx && rt_trace(ctx, rays[0].p, n, hits) == RT_OK; }
 };

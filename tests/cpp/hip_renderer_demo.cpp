@@ -1,6 +1,8 @@
 // Drives include/hip_renderer.hpp the way the reference's main() drives its Renderer
 // (src/main.cpp:388-621): LoadScene, BeginRender, poll IsRendering, read the RenderImage.
-//   hip_renderer_demo scene.xml W H spp seed out.bin
+//   hip_renderer_demo scene.xml W H spp seed out.bin [n_global n_caustic]
+// With the two photon counts the frame is the Whitted-style shader of the project-12 snapshot reading photon maps
+// (indirect light + caustics, 3 bounces) that FillPhotonMaps traces first.
 // out.bin = rgb (3 B/px) | z (f32) | sample counts (i32) | object ids (i32) | one hit record + one shadow flag
 #include "hip_renderer.hpp"
 
@@ -10,7 +12,7 @@
 
 int main(int argc, char **argv)
 {
-    if (argc != 7) { std::fprintf(stderr, "usage: %s scene.xml W H spp seed out.bin\n", argv[0]); return 2; }
+    if (argc != 7 && argc != 9) { std::fprintf(stderr, "usage: %s scene.xml W H spp seed out.bin [n_global n_caustic]\n", argv[0]); return 2; }
     rt::HipRenderer renderer(0);
     if (!renderer.Ok()) return 3;
     if (renderer.LoadScene("/nonexistent/scene.xml")) return 4; // must fail politely, like the reference
@@ -20,6 +22,17 @@ int main(int argc, char **argv)
     if (!renderer.SetCamera()) return 6;
     renderer.Params().min_spp = renderer.Params().max_spp = std::atoi(argv[4]);
     renderer.Params().seed = std::strtoull(argv[5], nullptr, 10);
+
+    if (argc == 9) {
+        rt_photon_params pp{};
+        pp.flags = RT_PM_INDIRECT | RT_PM_CAUSTICS;
+        pp.n_global = (uint32_t)std::atoi(argv[7]); pp.n_caustic = (uint32_t)std::atoi(argv[8]);
+        pp.max_segments = 64; pp.seed = renderer.Params().seed;
+        if (!renderer.FillPhotonMaps(pp)) return 9;
+        if (renderer.GetPhotonMap().size() != pp.n_global || renderer.GetCausticsMap().size() != pp.n_caustic) return 10;
+        renderer.Params().mode = RT_MODE_WHITTED;
+        renderer.Params().max_bounces = 3;
+    }
 
     renderer.BeginRender();
     while (renderer.IsRendering()) std::this_thread::sleep_for(std::chrono::milliseconds(1));

@@ -420,3 +420,27 @@ def test_cpp_renderer_mirror_matches_binding(tmp_path, ctx):
     hit = ctx.trace(ray)[0]
     assert (rec[0] == hit["z"] or (hit["node"] == -1 and rec[0] == -1.0)) and int(rec[1]) == hit["node"]
     assert int(rec[3]) == int(ctx.trace_shadow(ray, np.array([1e30], np.float32))[0])
+
+
+def test_cpp_renderer_mirror_photon_maps(tmp_path, ctx):
+    """HipRenderer::FillPhotonMaps / GetPhotonMap and a Whitted-style frame reading the maps, against the binding."""
+    import os
+    import subprocess
+    from raytracer_amd import scenes
+    exe = os.path.join(O.ROOT, "raytracer_amd", "hip_renderer_demo")
+    (tmp_path / "scene.xml").write_text(scenes.nested_scene_xml(64, 36).replace('<dof value="0.6"/>', ""))
+    w, h, spp, seed, ng, nc = 64, 36, 2, 23, 1500, 300
+    r = subprocess.run([exe, "scene.xml", str(w), str(h), str(spp), str(seed), "out.bin", str(ng), str(nc)], cwd=tmp_path,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    raw = np.fromfile(tmp_path / "out.bin", np.uint8)
+    rgb = raw[:3 * w * h].reshape(h, w, 3)
+    hs = lib.HostScene.from_file(str(tmp_path / "scene.xml"))
+    ctx.upload(hs.desc)
+    ctx.set_camera(hs.camera, w, h)
+    pp = abi.PhotonParams(flags=abi.RT_PM_INDIRECT | abi.RT_PM_CAUSTICS, n_global=ng, n_caustic=nc, max_segments=64, seed=seed)
+    ctx.photons_fill(pp)
+    fr = ctx.render(abi.default_params(seed=seed, min_spp=spp, max_spp=spp, max_bounces=3, mode=abi.RT_MODE_WHITTED,
+                                       photon_flags=pp.flags, gather_radius=3.0))
+    assert np.array_equal(rgb, fr.rgb)
+    assert fr.rgb.std() > 5  # a picture, not a constant
