@@ -57,7 +57,10 @@ def main():
         dirs = (d[None] + sx * x[None] + sy * y[None]).astype(np.float32)
         rays = np.concatenate([np.broadcast_to(pos, dirs.shape), dirs], 1).astype(np.float32)
         hits = ctx.trace(rays)
-        ok = hits["node"] >= 0
+        # only where the shader looks photons up: surfaces with a diffuse colour (MtlBlinn::IsPhotonSurface)
+        diffuse = np.array([sum(s.desc.materials[s.desc.nodes[i].material].diffuse[:]) > 0 if s.desc.nodes[i].prim else False
+                            for i in range(s.desc.n_nodes)])
+        ok = (hits["node"] >= 0) & diffuse[np.maximum(hits["node"], 0)]
         P = hits["p"][ok]
         N = hits["n"][ok]
         N /= np.linalg.norm(N, axis=1, keepdims=True)
