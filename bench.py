@@ -43,6 +43,8 @@ WORKLOADS = {
     "mesh_1m_1080p_64spp": (1000, 500, 1920, 1080, 64),   # the headline configuration
     "mesh_64k_540p_8spp": (250, 128, 960, 540, 8),        # development size
     "mesh_10m_4k_adaptive": (5000, 1000, 3840, 2160, (16, 256)),  # 10M triangles, 4K, 16..256 spp with the variance stop
+    # the reference's shipped scene exactly as it renders it: 1280x720, 128 spp, 50 bounces (ms/frame is the number to read)
+    "scene_a_720p_128spp": ("fixture", "scene_a", 1280, 720, 128),
     # Whitted-style shader (project-12 snapshot): Blinn-Phong + adaptive soft shadows, no recursion
     "spheres_1080p_16spp_whitted": ("spheres", 8, 1920, 1080, 16),
     # photon maps: 10M + 1M photons traced, balanced and gathered from, 16..64 spp adaptive, 5 bounces
@@ -59,6 +61,10 @@ def build_scene(name):
     spp = spp if isinstance(spp, tuple) else (spp, spp)
     if kind == "spheres":
         return lib.HostScene.from_string(scenes.spheres_scene_xml(grid=arg, width=w, height=h)), w, h, spp, 0, abi.RT_MODE_WHITTED, 0, None
+    if kind == "fixture":
+        hs = abi.scene_from_fixture(dict(np.load(os.path.join(ROOT, "tests", "golden", arg + ".npz"))))
+        hs.camera.width, hs.camera.height = w, h
+        return hs, w, h, spp, 0, abi.RT_MODE_PATH, 50, None
     if kind == "photons":
         # the reference's own scene (its Cornell box with mirror, glass and glossy spheres), held as a flattened fixture
         hs = abi.scene_from_fixture(dict(np.load(os.path.join(ROOT, "tests", "golden", "scene_a.npz"))))

@@ -200,6 +200,27 @@ def test_whitted_spheres_vs_oracle(ctx, bounces, w, h, spp):
     assert abs(int(c.shadow_rays) - int(cpu.stats.shadow)) <= 5e-3 * cpu.stats.shadow
 
 
+def test_whitted_tile_shards_and_determinism(ctx):
+    """Whitted-style frames with photon maps: rendering twice gives the same bits, and three tile shards tile the frame."""
+    s = O.scene_from_golden(O.load_golden("scene_a"))
+    w, h = 200, 120
+    ctx.upload(s.desc)
+    ctx.set_camera(s.camera, w, h)
+    pp = abi.PhotonParams(flags=abi.RT_PM_INDIRECT | abi.RT_PM_CAUSTICS, n_global=5000, n_caustic=1000, max_segments=64, seed=3)
+    ctx.photons_fill(pp)
+    kw = dict(seed=3, min_spp=2, max_spp=6, delta_max=0.05, max_bounces=3, mode=abi.RT_MODE_WHITTED, photon_flags=pp.flags)
+    whole = ctx.render(abi.default_params(**kw))
+    again = ctx.render(abi.default_params(**kw))
+    merged = lib.Frame(w, h)
+    for rank in range(3):
+        ctx.render(abi.default_params(tile_rank=rank, tile_world=3, **kw), merged)
+    for k in ("rgb", "z", "sample_count", "object_id"):
+        assert np.array_equal(getattr(whole, k), getattr(again, k)), f"{k} not deterministic"
+        assert np.array_equal(getattr(whole, k), getattr(merged, k)), f"{k}: shards do not tile the frame"
+    assert np.array_equal(bits(whole.linear), bits(again.linear))
+    assert len(np.unique(whole.sample_count)) > 1  # the variance stop test released pixels at different counts
+
+
 def test_whitted_rejects_deep_recursion(ctx):
     s = O.scene_from_golden(O.load_golden("scene_a"))
     ctx.upload(s.desc)
