@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 2
+#define RT_ABI_VERSION 3
 
 typedef struct rt_ctx rt_ctx;
 
@@ -99,7 +99,23 @@ typedef struct rt_material {
     float refraction[3];
     float absorption[3];
     float ior;
+    int32_t diffuse_texture; /* 1 + index into rt_scene_desc.textures, 0 = none. The only material channel either
+                                renderer evaluates with its texture (the snapshot's Shade: diffuse.Eval(UVW),
+                                project12.zip src/materials.cpp:22; everything else reads GetValue()) */
 } rt_material;
+
+/* A TextureMap with its Texture (src/scene.h:294-362, src/texture.h, src/texture.cpp:100-134): uvw is taken into
+ * texture space by itm (TransformTo), tiled into [0,1), then either a checkerboard of two colours or an 8-bit RGB
+ * image with bilinear filtering is evaluated.  The owning TexturedColor multiplies the result by its value. */
+typedef enum rt_texture_type { RT_TEX_CHECKER = 1, RT_TEX_IMAGE = 2 } rt_texture_type;
+typedef struct rt_texture {
+    int32_t type;          /* rt_texture_type */
+    float itm[12];         /* inverse of the texture transformation, 3x4 column-major */
+    float color1[3];       /* checkerboard: colour where exactly one of u, v is <= 0.5 is color2, else color1 */
+    float color2[3];
+    const uint8_t *pixels; /* image: [height*width*3], row 0 first (Color24) */
+    int32_t width, height;
+} rt_texture;
 
 /* Light (reference: AmbientLight/DirectLight/PointLight, src/lights.h). */
 typedef struct rt_light {
@@ -116,8 +132,13 @@ typedef struct rt_scene_desc {
     const rt_mesh *meshes;        uint32_t n_meshes;
     const rt_material *materials; uint32_t n_materials;
     const rt_light *lights;       uint32_t n_lights;
-    float background[3];  /* constant background colour (src/scene.h:502) */
-    float environment[3]; /* constant environment colour (src/scene.h:503) */
+    float background[3];  /* background colour (src/scene.h:502): what a camera ray sees that hits nothing */
+    float environment[3]; /* environment colour (src/scene.h:503): what a secondary ray of the Whitted-style shader sees then */
+    const rt_texture *textures;  uint32_t n_textures;
+    int32_t background_texture;  /* 1 + index into textures, 0 = none: colour * texture. The path tracer evaluates it at
+                                    uvw = ray direction (src/main.cpp:175), the Whitted-style shader at the pixel's
+                                    (u, v, 1) (project12.zip src/main.cpp:224-226) */
+    int32_t environment_texture; /* likewise, evaluated through EvalEnvironment (src/scene.h:390-397) */
 } rt_scene_desc;
 
 /* Camera as the reference holds it after Camera::Load (src/scene.h:458-480,

@@ -107,8 +107,29 @@ def photons():
         save(name, **sa, params=np.array([seed, mn, mx, w, h, bounces, ng, nc, seg, flags], np.int64), delta=np.float32(delta), **img)
 
 
+def textures():
+    """A scene with checkerboard and image textures on a material, the background and the environment: the reference's
+    scene dump with its texture maps and known-answer lookups, a path-traced image (HEAD) and a Whitted-style one (snapshot)."""
+    with tempfile.TemporaryDirectory() as tmp:
+        img = scenes.texture_image()
+        scenes.write_ppm(os.path.join(tmp, "tex.ppm"), img)
+        xml = scenes.textured_scene_xml("tex.ppm", 96, 54)
+        p = os.path.join(tmp, "textured.xml")
+        open(p, "w").write(xml)
+        common = dict(xml=np.frombuffer(xml.encode(), np.uint8), image=img)
+        st = scene_bundle(p, cwd=tmp)
+        out = run(p, "render", 7, 8, 8, 0.01, 96, 54, cwd=tmp)
+        save("image_textured_96x54_s8", **common, **st, params=np.array([7, 8, 8, 96, 54], np.int64), delta=np.float32(0.01), **out)
+        H = HARNESS_P12
+        st12 = scene_bundle(p, cwd=tmp, harness=H)
+        out = run(p, "render_whitted", 7, 4, 4, 0.01, 96, 54, 5, cwd=tmp, harness=H)
+        save("whitted_textured_96x54_b5", **common, **st12, params=np.array([7, 4, 4, 96, 54, 5], np.int64), delta=np.float32(0.01), **out)
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
+    if "--textures" in sys.argv:
+        return textures()
     if "--whitted" in sys.argv:  # only the snapshot's fixtures
         return whitted()
     if "--photons" in sys.argv:
@@ -163,6 +184,7 @@ def main():
         save("image_mesh_96x54_s8", **small, params=np.array([7, 8, 8, 96, 54], np.int64), delta=np.float32(0.01), **img)
     whitted()
     photons()
+    textures()
 
 
 if __name__ == "__main__":

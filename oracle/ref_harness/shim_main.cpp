@@ -31,6 +31,7 @@ std::ostream &operator<<(std::ostream &os, std::chrono::duration<R, P> const &d)
 #undef main
 
 #include "objects.h"
+#include "texture.h"
 #include "materials.h" // the snapshot's main.cpp does not pull it in
 
 #include <cstdio>
@@ -188,6 +189,64 @@ static void cmdDumpScene()
     Color bg = sc.background.GetValue();
     std::vector<float> b = { bg.r, bg.g, bg.b };
     dumpF("background", b, {3});
+
+    Color en = sc.environment.GetValue();
+    std::vector<float> e3 = { en.r, en.g, en.b };
+    dumpF("environment", e3, {3});
+
+    // textures: the maps of background, environment and every material's diffuse colour, with known-answer lookups
+    {
+        struct Owner { int kind, index; const TextureMap *map; };
+        std::vector<Owner> owners;
+        if (sc.background.GetTexture()) owners.push_back({0, 0, sc.background.GetTexture()});
+        if (sc.environment.GetTexture()) owners.push_back({1, 0, sc.environment.GetTexture()});
+        for (size_t k = 0; k < nm; ++k) {
+            const MtlBasePhongBlinn *b = static_cast<const MtlBasePhongBlinn *>(sc.materials[k]);
+            if (b->Diffuse().GetTexture()) owners.push_back({2, (int)k, b->Diffuse().GetTexture()});
+        }
+        const size_t nt = owners.size(), nq = 256;
+        std::vector<int32_t> own(nt * 2), type(nt), size(nt * 2, 0);
+        std::vector<float> itm_(nt * 12), cols(nt * 6, 0.0f), uvw(nt * nq * 3), rgb(nt * nq * 3);
+        RNG g(123, 5);
+        for (size_t t = 0; t < nt; ++t) {
+            const TextureMap *m = owners[t].map;
+            own[t * 2] = owners[t].kind; own[t * 2 + 1] = owners[t].index;
+            memcpy(&itm_[t * 12], m->GetInverseTransform().cell, 48);
+            const Texture *tx = m->texture;
+            if (auto *c = dynamic_cast<const TextureChecker *>(tx)) {
+                type[t] = 1;
+                Color a = c->color[0].GetValue(), b = c->color[1].GetValue();
+                float *d = &cols[t * 6]; d[0] = a.r; d[1] = a.g; d[2] = a.b; d[3] = b.r; d[4] = b.g; d[5] = b.b;
+            } else if (auto *f = dynamic_cast<const TextureFile *>(tx)) {
+                type[t] = 2;
+                size[t * 2] = f->width; size[t * 2 + 1] = f->height;
+                std::vector<uint8_t> px((size_t)f->width * f->height * 3);
+                memcpy(px.data(), f->data.data(), px.size());
+                char nm_[32]; snprintf(nm_, sizeof nm_, "tex%zu_pixels", t);
+                dumpB(nm_, px, {(size_t)f->height, (size_t)f->width, 3});
+            }
+            for (size_t q = 0; q < nq; ++q) {
+                Vec3f p{ (g.RandomFloat() - 0.5f) * 8.0f, (g.RandomFloat() - 0.5f) * 8.0f, (g.RandomFloat() - 0.5f) * 8.0f };
+                if (q % 4 == 0) p = Vec3f{ g.RandomFloat(), g.RandomFloat(), 0.0f };
+                Color c = m->Eval(p);
+                memcpy(&uvw[(t * nq + q) * 3], &p.x, 12);
+                rgb[(t * nq + q) * 3] = c.r; rgb[(t * nq + q) * 3 + 1] = c.g; rgb[(t * nq + q) * 3 + 2] = c.b;
+            }
+        }
+        dumpI("tex_owner", own, {nt, 2}); dumpI("tex_type", type, {nt}); dumpI("tex_size", size, {nt, 2});
+        dumpF("tex_itm", itm_, {nt, 12}); dumpF("tex_colors", cols, {nt, 6});
+        dumpF("tex_kat_uvw", uvw, {nt, nq, 3}); dumpF("tex_kat_rgb", rgb, {nt, nq, 3});
+        // EvalEnvironment for random directions
+        std::vector<float> ed(nq * 3), ec(nq * 3);
+        for (size_t q = 0; q < nq; ++q) {
+            Vec3f d{ g.RandomFloat() - 0.5f, g.RandomFloat() - 0.5f, g.RandomFloat() - 0.5f };
+            if (q & 1) d *= 7.0f;
+            Color c = sc.environment.EvalEnvironment(d);
+            memcpy(&ed[q * 3], &d.x, 12);
+            ec[q * 3] = c.r; ec[q * 3 + 1] = c.g; ec[q * 3 + 2] = c.b;
+        }
+        dumpF("env_kat_dir", ed, {nq, 3}); dumpF("env_kat_rgb", ec, {nq, 3});
+    }
 
     // meshes + BVH
     for (size_t k = 0; k < sc.objList.size(); ++k) {

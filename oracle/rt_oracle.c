@@ -159,6 +159,81 @@ float orc_halton(int index, int base) /* rng.h:103-112 */
     return r;
 }
 
+
+/* ------------------------------------------------------------------------- */
+/* textures (src/scene.h:294-402, src/texture.cpp:100-134)                    */
+/* ------------------------------------------------------------------------- */
+static v3 tile_clamp(v3 uvw) /* scene.h:322-332 */
+{
+    v3 u;
+    u.x = uvw.x - (float)(int)uvw.x;
+    u.y = uvw.y - (float)(int)uvw.y;
+    u.z = uvw.z - (float)(int)uvw.z;
+    if (u.x < 0) u.x += 1;
+    if (u.y < 0) u.y += 1;
+    if (u.z < 0) u.z += 1;
+    return u;
+}
+
+/* TextureMap::Eval(uvw) -> Texture::Eval(TransformTo(uvw)) (scene.h:346, texture.cpp:100-134) */
+static v3 texture_eval(const rt_texture *t, v3 uvw_in)
+{
+    const v3 uvw = m34_mul(t->itm, uvw_in);
+    const v3 u = tile_clamp(uvw);
+    if (t->type == RT_TEX_CHECKER) return ((u.x <= 0.5f) ^ (u.y <= 0.5f)) ? vld(t->color2) : vld(t->color1);
+    const int width = t->width, height = t->height;
+    if (width + height == 0) return V3(0, 0, 0);
+    const float x = width * u.x;
+    const float y = height * u.y;
+    int ix = (int)x;
+    int iy = (int)y;
+    const float fx = x - ix;
+    const float fy = y - iy;
+    if (ix < 0) ix -= (ix / width - 1) * width;
+    if (ix >= width) ix -= (ix / width) * width;
+    int ixp = ix + 1;
+    if (ixp >= width) ixp -= width;
+    if (iy < 0) iy -= (iy / height - 1) * height;
+    if (iy >= height) iy -= (iy / height) * height;
+    int iyp = iy + 1;
+    if (iyp >= height) iyp -= height;
+#define TEXEL(X, Y) V3(t->pixels[((size_t)(Y) * width + (X)) * 3] / 255.0f, t->pixels[((size_t)(Y) * width + (X)) * 3 + 1] / 255.0f, \
+                       t->pixels[((size_t)(Y) * width + (X)) * 3 + 2] / 255.0f)
+    v3 c = vscale(TEXEL(ix, iy), (1 - fx) * (1 - fy));
+    c = vadd(c, vscale(TEXEL(ixp, iy), fx * (1 - fy)));
+    c = vadd(c, vscale(TEXEL(ix, iyp), (1 - fx) * fy));
+    c = vadd(c, vscale(TEXEL(ixp, iyp), fx * fy));
+#undef TEXEL
+    return c;
+}
+
+/* TexturedColor::Eval (scene.h:386): value * map, or the value alone.  tex = 1 + index, 0 = none */
+static v3 textured_color(const rt_scene_desc *sc, const float value[3], int tex, v3 uvw)
+{
+    if (tex <= 0 || (uint32_t)tex > sc->n_textures) return vld(value);
+    return vmul(vld(value), texture_eval(&sc->textures[tex - 1], uvw));
+}
+
+/* TexturedColor::EvalEnvironment (scene.h:390-397) */
+static v3 textured_environment(const rt_scene_desc *sc, const float value[3], int tex, v3 dir)
+{
+    if (tex <= 0 || (uint32_t)tex > sc->n_textures) return vld(value);
+    const float len = vlen(dir);
+    const float z = asinf(-dir.z / len) / PI_F + 0.5f;
+    const float x = (float)(dir.x / (fabs(dir.x) + fabs(dir.y)));
+    const float y = (float)(dir.y / (fabs(dir.x) + fabs(dir.y)));
+    return textured_color(sc, value, tex, V3(0.5f + 0.5f * z * (x - y), 0.5f + 0.5f * z * (x + y), 0.0f));
+}
+void orc_environment_eval(const rt_scene_desc *sc, const float dir[3], float rgb[3])
+{
+    vst(rgb, textured_environment(sc, sc->environment, sc->environment_texture, vld(dir)));
+}
+void orc_texture_eval(const rt_scene_desc *sc, int tex, const float uvw[3], float rgb[3])
+{
+    const float one[3] = { 1.0f, 1.0f, 1.0f };
+    vst(rgb, textured_color(sc, one, tex, vld(uvw)));
+}
+
 /* ------------------------------------------------------------------------- */
 /* primitives                                                                */
 /* ------------------------------------------------------------------------- */
@@ -752,7 +827,7 @@ static void trace_path(const rt_scene_desc *sc, ray_t ray, orc_rng *rng, const r
     for (int bounce = 0; bounce < prm->max_bounces; ++bounce) {
         hit_t h; hit_init(&h);
         if (!trace_ray(sc, ray, &h, st)) {
-            result = vadd(result, vmul(vld(sc->background), throughput)); /* main.cpp:175-176, constant background */
+            result = vadd(result, vmul(textured_color(sc, sc->background, sc->background_texture, ray.d), throughput)); /* main.cpp:175-176: uvw = ray.dir */
             *result_out = result;
             return;
         }
@@ -1221,7 +1296,7 @@ typedef struct {
 } wctx;
 
 /* SamplerInfo::SetHit + what Shade reads from it (p12 renderer.h:146-154) */
-typedef struct { v3 p, n, v; int front; int bounce; } wshade;
+typedef struct { v3 p, n, v, uvw; int front; int bounce; } wshade;
 
 static v3 whitted_shade(const wctx *C, const wshade *s, const rt_material *m);
 
@@ -1269,18 +1344,17 @@ static v3 w_illuminate(const wctx *C, const rt_light *l, v3 P, v3 *dir)
     return vdivs(vdivs(vscale(I, (float)numHits), (float)64), distSquared);
 }
 
-/* TexturedColor::EvalEnvironment without a texture is the colour itself (scene.h:390-397) */
-static v3 w_environment(const wctx *C) { return vld(C->sc->environment); }
+static v3 w_environment(const wctx *C, v3 dir) { return textured_environment(C->sc, C->sc->environment, C->sc->environment_texture, dir); }
 
 /* ShadeInfo::TraceSecondaryRay (p12 main.cpp:132-155); the caller has checked CanBounce */
 static v3 w_secondary(const wctx *C, const wshade *from, ray_t ray, float *dist)
 {
     hit_t h; hit_init(&h);
-    if (!trace_ray(C->sc, ray, &h, C->st)) { *dist = BIGFLOAT; return w_environment(C); }
+    if (!trace_ray(C->sc, ray, &h, C->st)) { *dist = BIGFLOAT; return w_environment(C, ray.d); }
     *dist = h.z;
     if (h.light) return V3(1.0f, 1.0f, 1.0f);
     wshade s;
-    s.p = h.p; s.n = vnormalize(h.n); s.v = vneg(vnormalize(ray.d)); s.front = h.front; s.bounce = from->bounce + 1;
+    s.p = h.p; s.n = vnormalize(h.n); s.v = vneg(vnormalize(ray.d)); s.uvw = h.uvw; s.front = h.front; s.bounce = from->bounce + 1;
     return whitted_shade(C, &s, &C->sc->materials[C->sc->nodes[h.node].material]);
 }
 
@@ -1293,7 +1367,7 @@ static v3 whitted_shade(const wctx *C, const wshade *s, const rt_material *m)
     const rt_scene_desc *sc = C->sc;
     v3 final = vld(m->emission);
     const v3 normal = vnormalize(s->n);
-    const v3 diffuseColor = vld(m->diffuse);
+    const v3 diffuseColor = textured_color(sc, m->diffuse, m->diffuse_texture, s->uvw); /* diffuse.Eval(shadeInfo.UVW()) */
     const v3 specular = vld(m->specular);
     const float gloss = m->glossiness;
     const int pm = C->prm->photon_flags;
@@ -1410,15 +1484,19 @@ static v3 whitted_shade(const wctx *C, const wshade *s, const rt_material *m)
 
 /* one sample of the p12 pixel loop after the camera ray has been built (p12 main.cpp:212-231) */
 static v3 whitted_sample(const rt_scene_desc *sc, const rt_render_params *prm, const float (*halton)[64], ray_t ray,
-                         int pixel_x, orc_rng *rng, orc_stats *st)
+                         int pixel_x, int pixel_y, int k, int W, int H, orc_rng *rng, orc_stats *st)
 {
     wctx C = { sc, prm, halton, pixel_x, rng, st };
     if (st) st->paths++;
     hit_t h; hit_init(&h);
-    if (!trace_ray(sc, ray, &h, st)) return vld(sc->background); /* constant background: Eval(u,v,1) without a texture */
+    if (!trace_ray(sc, ray, &h, st)) { /* p12 main.cpp:224-226: the un-jittered Halton point of the sample, not the ray */
+        const float u = ((float)pixel_x + halton[0][k % prm->halton_period]) / (float)(W - 1);
+        const float v = ((float)pixel_y + halton[1][k % prm->halton_period]) / (float)(H - 1);
+        return textured_color(sc, sc->background, sc->background_texture, V3(u, v, 1.0f));
+    }
     if (h.light) return V3(1.0f, 1.0f, 1.0f);
     wshade s;
-    s.p = h.p; s.n = vnormalize(h.n); s.v = vneg(vnormalize(ray.d)); s.front = h.front; s.bounce = 0;
+    s.p = h.p; s.n = vnormalize(h.n); s.v = vneg(vnormalize(ray.d)); s.uvw = h.uvw; s.front = h.front; s.bounce = 0;
     return whitted_shade(&C, &s, &sc->materials[sc->nodes[h.node].material]);
 }
 
@@ -1508,7 +1586,7 @@ static void render_pixel(job_t *J, int i, int j, orc_stats *st)
             if (J->out->object_id) J->out->object_id[o] = hit ? h.node : -1;
         }
         v3 c;
-        if (prm->mode == RT_MODE_WHITTED) c = whitted_sample(J->sc, prm, (const float (*)[64])J->halton, ray, i, &rng, st);
+        if (prm->mode == RT_MODE_WHITTED) c = whitted_sample(J->sc, prm, (const float (*)[64])J->halton, ray, i, j, k, W, cam->height, &rng, st);
         else trace_path(J->sc, ray, &rng, prm, &c, st);
         sum = vadd(sum, c);
         sumSq = vadd(sumSq, vmul(c, c));

@@ -76,6 +76,11 @@ uint64_t orc_photon_irradiance(const rt_photon *tree, uint32_t n, const float po
 /* the maps orc_render's Whitted-style shader reads when prm->photon_flags != 0 (not copied) */
 void orc_set_photon_map(int which, const rt_photon *tree, uint32_t n);
 
+/* TextureMap::Eval of texture `tex` (1 + index into sc->textures) at uvw (src/scene.h:346, src/texture.cpp:100-134) */
+void orc_texture_eval(const rt_scene_desc *sc, int tex, const float uvw[3], float rgb[3]);
+/* TexturedColor::EvalEnvironment of the scene's environment for a direction (src/scene.h:390-397) */
+void orc_environment_eval(const rt_scene_desc *sc, const float dir[3], float rgb[3]);
+
 /* sRGB + 8-bit quantisation (cyColor.h:98,324-325) */
 void orc_resolve_pixel(const float linear[3], int srgb, uint8_t rgb[3]);
 

@@ -39,7 +39,12 @@ class Mesh(C.Structure):
 class Material(C.Structure):
     _fields_ = [("diffuse", C.c_float * 3), ("specular", C.c_float * 3), ("glossiness", C.c_float),
                 ("emission", C.c_float * 3), ("reflection", C.c_float * 3), ("refraction", C.c_float * 3),
-                ("absorption", C.c_float * 3), ("ior", C.c_float)]
+                ("absorption", C.c_float * 3), ("ior", C.c_float), ("diffuse_texture", C.c_int32)]
+
+
+class Texture(C.Structure):
+    _fields_ = [("type", C.c_int32), ("itm", C.c_float * 12), ("color1", C.c_float * 3), ("color2", C.c_float * 3),
+                ("pixels", C.POINTER(C.c_uint8)), ("width", C.c_int32), ("height", C.c_int32)]
 
 
 class Light(C.Structure):
@@ -52,7 +57,9 @@ class SceneDesc(C.Structure):
                 ("meshes", C.POINTER(Mesh)), ("n_meshes", C.c_uint32),
                 ("materials", C.POINTER(Material)), ("n_materials", C.c_uint32),
                 ("lights", C.POINTER(Light)), ("n_lights", C.c_uint32),
-                ("background", C.c_float * 3), ("environment", C.c_float * 3)]
+                ("background", C.c_float * 3), ("environment", C.c_float * 3),
+                ("textures", C.POINTER(Texture)), ("n_textures", C.c_uint32),
+                ("background_texture", C.c_int32), ("environment_texture", C.c_int32)]
 
 
 class Camera(C.Structure):
@@ -78,6 +85,7 @@ PHOTON_DTYPE = np.dtype([("pos", "<f4", 3), ("power", "<f4"), ("dir", "<f4", 3),
 assert PHOTON_DTYPE.itemsize == 32
 RT_PM_DIRECT, RT_PM_INDIRECT, RT_PM_CAUSTICS, RT_PM_MONTE_CARLO = 1, 2, 4, 8
 RT_MAP_GLOBAL, RT_MAP_CAUSTICS = 0, 1
+RT_TEX_CHECKER, RT_TEX_IMAGE = 1, 2
 
 
 class FrameOut(C.Structure):

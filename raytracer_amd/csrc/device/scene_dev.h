@@ -41,6 +41,15 @@ struct DMesh {
     uint32_t depth;
 };
 
+// One texture map (rt_texture with its pixels in device memory).
+struct DTexture {
+    int32_t type;
+    float itm[12];
+    float color1[3], color2[3];
+    const uint8_t *pixels;
+    int32_t width, height;
+};
+
 struct DScene {
     const DNode *nodes;
     const DMesh *meshes;
@@ -55,6 +64,8 @@ struct DScene {
     uint2 *stack_overflow; // [(stack_levels - lds_levels)][threads of the largest grid]
     const rt_photon *pmap[2]; // balanced photon maps (global, caustics), node 1 first; null when not built
     uint32_t pmap_n[2];
+    const DTexture *textures;
+    int32_t background_texture, environment_texture; // 1 + index, 0 = none
     uint2 *gather_heaps; // [threads of the largest grid][130]: the lanes' heaps of nearest photons
 };
 

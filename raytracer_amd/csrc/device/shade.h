@@ -4,6 +4,7 @@
 // tracePath (src/main.cpp:160-268).  The order of random draws is part of the
 // contract: light r1, light phi, lobe, then two (or three) draws of the lobe.
 #pragma once
+#include "texture.h"
 #include "trace.h"
 
 #ifdef RT_ABLATE_NATIVE_MATH // timing experiment only: hardware approximations, results change
@@ -243,7 +244,7 @@ RT_DEV bool path_step(const DScene &S, const DFrame &F, PathState &ps, LaneStack
     pt.tock(0);
     if (ps.bounce == 0 && first_z) { *first_z = h.z; *first_id = hit ? h.node : -1; }
     if (!hit) {
-        ps.result = ps.result + ld3(S.background) * ps.throughput; // main.cpp:175-176
+        ps.result = ps.result + textured_color(S, S.background, S.background_texture, ray.d) * ps.throughput; // main.cpp:175-176: uvw = ray.dir
         return false;
     }
     if (h.node < 0) { // light (main.cpp:184-210)

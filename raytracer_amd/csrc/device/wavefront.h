@@ -111,7 +111,7 @@ RT_DEV uint32_t wf_shade_slot(const DScene &S, const DFrame &F, const WfPool &P,
             }
             if (status == WF_PROBE) finished = true; // zero bounces: the camera ray was traced for the planes only
             else if (!hit) {
-                ps.result = ps.result + ld3(S.background) * ps.throughput; // main.cpp:175-176
+                ps.result = ps.result + textured_color(S, S.background, S.background_texture, ray.d) * ps.throughput; // main.cpp:175-176
                 finished = true;
             } else if (h.node < 0) { // light (main.cpp:184-210)
                 const V3 rad = light_radiance(light);

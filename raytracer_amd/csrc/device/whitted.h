@@ -33,6 +33,7 @@ struct WFrame {
     V3 final;      // colour accumulated so far
     V3 p, n, v;    // hit point, unit normal, unit view vector (SamplerInfo::SetHit, p12 renderer.h:146-154)
     V3 h;          // sampled half vector of the refraction lobe
+    V3 kd;         // diffuse colour at the hit: diffuse.Eval(UVW), the one textured channel (p12 materials.cpp:22)
     float dist;    // ray parameter of the hit that created this frame
     uint32_t meta; // material index | front << 20 | pending combination << 24
 };
@@ -43,7 +44,7 @@ RT_DEV void whitted_light_term(WFrame &f, const rt_material &m, V3 lightIntensit
 {
     const V3 normal = f.n;
     const float geometryTerm = std_max(0.0f, dot(normal, lightDir));
-    f.final = f.final + ((ld3(m.diffuse) * kInvPiF) * lightIntensity) * geometryTerm;
+    f.final = f.final + ((f.kd * kInvPiF) * lightIntensity) * geometryTerm;
     const V3 halfway = normalize(f.v + lightDir);
     const float blinnTerm = std_max(0.0f, dot(normal, halfway));
     const float k = (float)((double)(m.glossiness + 2.0f) / kEightPi);
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_whitted(DScene S, DFrame F, const
         const uint64_t parked = __ballot(state == W_GATHER);
         if (parked != 0 && (__popcll(parked) >= kGatherQuorum || !__any(state == W_TRACE || state == W_SHADOW))) {
             if (state == W_GATHER) {
-                const V3 kd = ld3(S.materials[mtl].diffuse) * kInvPiF;
+                const V3 kd = cur.kd * kInvPiF;
                 u32x2 *heap = lane_heap(S);
                 if (pm & (RT_PM_DIRECT | RT_PM_INDIRECT)) {
                     cur.final = cur.final + kd * photon_irradiance<COUNT>(S.pmap[0], S.pmap_n[0], cur.p, cur.n, F.gather_radius, st, heap, visits);
@@ -180,7 +181,12 @@ __global__ __launch_bounds__(kBlock, 4) void k_whitted(DScene S, DFrame F, const
             const bool hit = trace_closest<COUNT, LEVELS>(S, ray, st, h, tl);
             if (depth == 0) { fz = h.z; fid = hit ? h.node : -1; }
             if (!hit) {
-                ret = depth == 0 ? ld3(S.background) : ld3(S.environment);
+                if (depth == 0) { // p12 main.cpp:224-226: the background at the sample's un-jittered Halton point
+                    const int hk = k % period;
+                    const float u = ((float)(pix % F.width) + halton[hk]) / (float)(F.width - 1);
+                    const float v = ((float)(pix / F.width) + halton[64 + hk]) / (float)(F.height - 1);
+                    ret = textured_color(S, S.background, S.background_texture, mk(u, v, 1.0f));
+                } else ret = textured_environment(S, S.environment, S.environment_texture, ray.d);
                 retDist = FLT_MAX;
                 state = W_RET;
             } else if (h.node < 0) { // a light seen directly is white (p12 main.cpp:147,228)
@@ -188,14 +194,16 @@ __global__ __launch_bounds__(kBlock, 4) void k_whitted(DScene S, DFrame F, const
                 retDist = h.z;
                 state = W_RET;
             } else {
-                finish_hit(S, ray, h, false);
+                mtl = S.nodes[h.node].material;
+                const rt_material &hm = S.materials[mtl];
+                finish_hit(S, ray, h, hm.diffuse_texture > 0);
+                cur.kd = textured_color(S, hm.diffuse, hm.diffuse_texture, h.uvw);
                 cur.p = h.p;
                 cur.n = normalize(normalize(h.n)); // SetHit normalises, Shade normalises again
                 cur.v = -normalize(ray.d);
                 cur.dist = h.z;
                 front = h.front;
-                mtl = S.nodes[h.node].material;
-                cur.final = ld3(S.materials[mtl].emission);
+                cur.final = ld3(hm.emission);
                 stage = STG_LIGHT;
                 l = 0;
                 state = W_CTRL;
@@ -247,7 +255,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_whitted(DScene S, DFrame F, const
                 const rt_material &m = S.materials[mtl];
                 state = W_CTRL;
                 if (comb == COMB_MC) {
-                    const V3 colorSum = mk(0, 0, 0) + ret * ld3(m.diffuse);
+                    const V3 colorSum = mk(0, 0, 0) + ret * cur.kd;
                     cur.final = cur.final + colorSum / 1.0f;
                     stage = STG_REFL;
                 } else if (comb == COMB_REFL) {
@@ -280,7 +288,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_whitted(DScene S, DFrame F, const
                 if (l >= S.n_lights || (pm & RT_PM_DIRECT)) { stage = STG_AFTER; continue; } // no light loop when the map holds the direct light
                 const rt_light &L = S.lights[l];
                 if (L.type == RT_LIGHT_AMBIENT) { // p12 lights.h:33, materials.cpp:28-31
-                    cur.final = cur.final + ld3(m.diffuse) * ld3(L.intensity);
+                    cur.final = cur.final + cur.kd * ld3(L.intensity);
                     ++l;
                     continue;
                 }
@@ -313,7 +321,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_whitted(DScene S, DFrame F, const
             }
             if (stage == STG_MC) { // Monte-Carlo indirect light on the first two bounces (p12 materials.cpp:74-103)
                 stage = STG_REFL;
-                if (!(pm & RT_PM_INDIRECT) && sum3(m.diffuse) > 0.0f && depth < 2) {
+                if (!(pm & RT_PM_INDIRECT) && (cur.kd.x + cur.kd.y + cur.kd.z) > 0.0f && depth < 2) {
                     const float phiOffset = rng_float(rng);
                     const float thetaOffset = rng_float(rng);
                     const float phi = (float)(kTwoPi * frac_sum(halton[ps_h], phiOffset));

@@ -40,6 +40,8 @@ struct rt_scene_host {
     std::vector<rt_material> materials;
     std::vector<std::string> material_names;
     std::vector<rt_light> lights;
+    std::vector<rt_texture> textures;
+    std::vector<std::vector<uint8_t>> texture_pixels; // per texture, empty for a checkerboard
     rt_scene_desc desc{};
     rt_camera camera{};
     std::vector<std::string> warnings;

@@ -7,6 +7,7 @@
 #include "xml_reader.h"
 
 #include <cctype>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <sys/stat.h>
@@ -19,6 +20,8 @@ void rt_scene_host::refresh_desc()
     desc.meshes = mesh_descs.data(); desc.n_meshes = (uint32_t)mesh_descs.size();
     desc.materials = materials.data(); desc.n_materials = (uint32_t)materials.size();
     desc.lights = lights.data(); desc.n_lights = (uint32_t)lights.size();
+    for (size_t i = 0; i < textures.size(); ++i) textures[i].pixels = texture_pixels[i].empty() ? nullptr : texture_pixels[i].data();
+    desc.textures = textures.data(); desc.n_textures = (uint32_t)textures.size();
 }
 
 namespace rt {
@@ -83,10 +86,81 @@ struct Loader {
 
     bool file_exists(const std::string &p) { struct stat st; return stat(p.c_str(), &st) == 0; }
 
+    // channels both renderers read with GetValue() only: a texture there has no effect in the reference either
     void textured(const XmlElement *e, const char *what)
     {
         if (e && e->attr("texture"))
-            S.warnings.push_back(std::string("texture on <") + what + "> ignored: textures are not part of the accelerated path");
+            S.warnings.push_back(std::string("texture on <") + what + "> has no effect: the renderers read this channel's value only");
+    }
+
+    // PPM (P6, maxval 255) as LoadPPM reads it (src/texture.cpp:36-58): magic line, comment lines, "W H", comment lines,
+    // the maxval line, then W*H RGB bytes
+    bool load_ppm(const std::string &path, int &w, int &h, std::vector<uint8_t> &px)
+    {
+        FILE *fp = fopen(path.c_str(), "rb");
+        if (!fp) return false;
+        auto line = [&](char *buf, int size) {
+            int i = 0;
+            for (; i < size; ++i) {
+                const int c = fgetc(fp);
+                if (c == EOF || c == '\n' || c == '\r') { buf[i] = '\0'; return; }
+                buf[i] = (char)c;
+            }
+            buf[size - 1] = '\0';
+        };
+        char buf[1024];
+        line(buf, sizeof buf);
+        bool ok = buf[0] == 'P' && buf[1] == '6';
+        if (ok) {
+            line(buf, sizeof buf);
+            while (buf[0] == '#') line(buf, sizeof buf);
+            ok = sscanf(buf, "%d %d", &w, &h) == 2 && w > 0 && h > 0 && (int64_t)w * h <= (1 << 28);
+        }
+        if (ok) {
+            line(buf, sizeof buf);
+            while (buf[0] == '#') line(buf, sizeof buf);
+            px.resize((size_t)w * h * 3);
+            ok = fread(px.data(), 3, (size_t)w * h, fp) == (size_t)w * h;
+        }
+        fclose(fp);
+        return ok;
+    }
+
+    // Loader::ReadTextureMap (xmlload.cpp:326-344): "checkerboard" with <color1>/<color2>, or an image file; the element's
+    // scale / rotate / translate children are the texture transformation.  Returns 1 + texture index, 0 = no texture.
+    int read_texture_map(const XmlElement *e)
+    {
+        const char *name = e ? e->attr("texture") : nullptr;
+        if (!name) return 0;
+        rt_texture t{};
+        std::vector<uint8_t> px;
+        if (ieq(name, "checkerboard")) {
+            t.type = RT_TEX_CHECKER;
+            t.color1[0] = t.color1[1] = t.color1[2] = 0.0f; // texture.h:50
+            t.color2[0] = t.color2[1] = t.color2[2] = 1.0f;
+            read_color(e->child("color1"), t.color1);
+            read_color(e->child("color2"), t.color2);
+            if ((e->child("color1") && e->child("color1")->attr("texture")) || (e->child("color2") && e->child("color2")->attr("texture")))
+                S.warnings.push_back("textures inside a checkerboard's colours are not supported: their values are used");
+        } else {
+            const size_t len = strlen(name);
+            std::string path = name;
+            if (!file_exists(path) && !base_dir.empty()) path = base_dir + "/" + name;
+            bool ok = false;
+            if (len >= 3 && ieq(name + len - 3, "ppm")) ok = load_ppm(path, t.width, t.height, px);
+            else S.warnings.push_back(std::string("texture ") + name + ": only PPM image files are read here (convert PNG files)");
+            if (!ok) { // the reference prints an error and goes on without the texture (xmlload.cpp:356-371)
+                S.warnings.push_back(std::string("cannot read texture file ") + name);
+                return 0;
+            }
+            t.type = RT_TEX_IMAGE;
+        }
+        Mat34 tm = Mat34::identity(), itm = Mat34::identity();
+        load_transform(*e, tm, itm);
+        memcpy(t.itm, itm.c, sizeof t.itm);
+        S.textures.push_back(t);
+        S.texture_pixels.push_back(std::move(px));
+        return (int)S.textures.size();
     }
 
     // Transformation::Load (xmlload.cpp:173-193): each child element pre-multiplies the node matrix
@@ -201,7 +275,7 @@ struct Loader {
         for (int i = 0; i < 3; ++i) { m.diffuse[i] = 0.5f; m.specular[i] = 0.7f; }
         m.glossiness = 20.0f;
         m.ior = 1.5f;
-        read_color(e.child("diffuse"), m.diffuse);       textured(e.child("diffuse"), "diffuse");
+        read_color(e.child("diffuse"), m.diffuse);       m.diffuse_texture = read_texture_map(e.child("diffuse"));
         read_color(e.child("specular"), m.specular);     textured(e.child("specular"), "specular");
         if (const XmlElement *g = e.child("glossiness")) { float f = 1.0f; read_float(g, f); m.glossiness = f; textured(g, "glossiness"); }
         read_color(e.child("emission"), m.emission);     textured(e.child("emission"), "emission");
@@ -266,8 +340,8 @@ struct Loader {
             if (ieq(t, "object")) { if (!load_node(*c, 0)) return false; }
             else if (ieq(t, "light")) load_light(*c);
             else if (ieq(t, "material")) load_material(*c);
-            else if (ieq(t, "background")) { read_color(c.get(), S.desc.background); textured(c.get(), "background"); }
-            else if (ieq(t, "environment")) { read_color(c.get(), S.desc.environment); textured(c.get(), "environment"); }
+            else if (ieq(t, "background")) { read_color(c.get(), S.desc.background); S.desc.background_texture = read_texture_map(c.get()); }
+            else if (ieq(t, "environment")) { read_color(c.get(), S.desc.environment); S.desc.environment_texture = read_texture_map(c.get()); }
             else S.warnings.push_back(std::string("unknown tag ") + t);
         }
         // SetNodeMaterials (xmlload.cpp:274-294): names resolved after all materials are known, exact match

@@ -51,7 +51,7 @@ struct rt_ctx {
     // scene
     bool have_scene = false;
     DScene scene{};
-    DeviceBuf d_nodes, d_meshes, d_materials, d_lights;
+    DeviceBuf d_nodes, d_meshes, d_materials, d_lights, d_textures;
     std::vector<std::unique_ptr<DeviceBuf>> mesh_bufs;
     std::vector<int> host_node_material; // for validation
     // camera
@@ -518,6 +518,27 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc)
         HIP_TRY(ctx, upload(m.vn, (size_t)m.nvn * 12, (const void **)&d.vn));
         HIP_TRY(ctx, upload(m.vt, (size_t)m.nvt * 12, (const void **)&d.vt));
     }
+    // ---- textures ----
+    const auto tex_ok = [&](int32_t t) { return t >= 0 && (uint32_t)t <= sc->n_textures; };
+    if (!tex_ok(sc->background_texture) || !tex_ok(sc->environment_texture)) return ctx->fail(RT_ERR_INVALID, "background / environment texture index out of range");
+    for (uint32_t i = 0; i < sc->n_materials; ++i)
+        if (!tex_ok(sc->materials[i].diffuse_texture)) return ctx->fail(RT_ERR_INVALID, "material %u: diffuse texture index out of range", i);
+    if (sc->n_textures > 0 && !sc->textures) return ctx->fail(RT_ERR_INVALID, "null texture array");
+    std::vector<DTexture> dtex(sc->n_textures);
+    for (uint32_t i = 0; i < sc->n_textures; ++i) {
+        const rt_texture &t = sc->textures[i];
+        DTexture &d = dtex[i];
+        memset(&d, 0, sizeof d);
+        d.type = t.type;
+        memcpy(d.itm, t.itm, sizeof d.itm); memcpy(d.color1, t.color1, 12); memcpy(d.color2, t.color2, 12);
+        if (t.type == RT_TEX_IMAGE) {
+            if (t.width < 0 || t.height < 0 || (int64_t)t.width * t.height > ((int64_t)1 << 28) || (t.width > 0 && t.height > 0 && !t.pixels) ||
+                ((t.width == 0) != (t.height == 0)))
+                return ctx->fail(RT_ERR_INVALID, "texture %u: bad image size or null pixels", i);
+            d.width = t.width; d.height = t.height;
+            if (t.width > 0) HIP_TRY(ctx, upload(t.pixels, (size_t)t.width * t.height * 3, (const void **)&d.pixels));
+        } else if (t.type != RT_TEX_CHECKER) return ctx->fail(RT_ERR_INVALID, "texture %u: unknown type %d", i, t.type);
+    }
     DScene S{};
     S.stack_levels = max_mesh_depth < 0 ? 0 : max_mesh_depth + 2;
     // LDS holds the first levels of every lane's stack (26 KiB per 256 threads lets six
@@ -539,6 +560,10 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc)
     HIP_TRY(ctx, ctx->d_lights.reserve(sizeof(rt_light) * sc->n_lights));
     HIP_TRY(ctx, hipMemcpy(ctx->d_lights.p, sc->lights, sizeof(rt_light) * sc->n_lights, hipMemcpyHostToDevice));
 
+    HIP_TRY(ctx, ctx->d_textures.reserve(sizeof(DTexture) * std::max<size_t>(1, dtex.size())));
+    if (!dtex.empty()) HIP_TRY(ctx, hipMemcpy(ctx->d_textures.p, dtex.data(), sizeof(DTexture) * dtex.size(), hipMemcpyHostToDevice));
+    S.textures = ctx->d_textures.as<DTexture>();
+    S.background_texture = sc->background_texture; S.environment_texture = sc->environment_texture;
     S.nodes = ctx->d_nodes.as<DNode>();
     S.meshes = ctx->d_meshes.as<DMesh>();
     S.materials = ctx->d_materials.as<rt_material>();

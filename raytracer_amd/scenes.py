@@ -261,3 +261,60 @@ def nested_scene_xml(width=320, height=180):
   </camera>
 </xml>
 """
+
+
+def texture_image(width=24, height=16, seed=5):
+    """A small RGB image (smooth gradients plus a little noise) as [h, w, 3] uint8."""
+    rng = np.random.RandomState(seed)
+    y, x = np.mgrid[0:height, 0:width]
+    img = np.stack([128 + 100 * np.sin(2 * np.pi * x / width), 128 + 100 * np.cos(2 * np.pi * y / height),
+                    255.0 * ((x // 4 + y // 4) % 2)], -1) + rng.randint(-20, 21, (height, width, 3))
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def write_ppm(path, img):
+    """Binary PPM (P6) as the reference's LoadPPM reads it."""
+    h, w, _ = img.shape
+    with open(path, "wb") as fp:
+        fp.write(b"P6\n# generated\n%d %d\n255\n" % (w, h))
+        fp.write(np.ascontiguousarray(img, np.uint8).tobytes())
+
+
+def textured_scene_xml(image="tex.ppm", width=96, height=54):
+    """Open scene that exercises every texture path: a checkerboard floor with a texture transformation, an image-mapped
+    sphere, mirror and glass spheres (secondary rays leave the scene: environment map), a textured background."""
+    return f"""<xml>
+  <scene>
+    <object type="plane" name="floor" material="checker"><scale value="30"/></object>
+    <object type="sphere" name="globe" material="mapped"><scale value="4"/><rotate angle="25" z="1"/><translate x="-7" y="2" z="4"/></object>
+    <object type="sphere" name="mirror" material="mirror"><scale value="3.5"/><translate x="1" y="5" z="3.5"/></object>
+    <object type="sphere" name="glass" material="glass"><scale value="3"/><translate x="7" y="-2" z="3"/></object>
+    <material type="blinn" name="checker">
+      <diffuse value="0.8" texture="checkerboard">
+        <color1 r="0.9" g="0.2" b="0.1"/><color2 value="0.95"/>
+        <scale x="0.25" y="0.125" z="1"/><rotate angle="30" z="1"/><translate x="0.1" y="0.2"/>
+      </diffuse>
+      <specular value="0.1"/><glossiness value="40"/>
+    </material>
+    <material type="blinn" name="mapped">
+      <diffuse value="0.9" texture="{image}"><scale x="0.5" y="1" z="1"/></diffuse>
+      <specular value="0.2"/><glossiness value="30"/>
+    </material>
+    <material type="blinn" name="mirror"><diffuse value="0"/><specular value="0.8"/><glossiness value="300"/><reflection value="0.8"/></material>
+    <material type="blinn" name="glass"><diffuse value="0"/><specular value="0.1"/><glossiness value="800"/><refraction value="0.9" index="1.5"/></material>
+    <light type="point" name="lamp"><intensity value="900"/><position x="-4" y="-8" z="24"/><size value="1.5"/></light>
+    <background r="0.6" g="0.7" b="1.0" texture="checkerboard">
+      <color1 value="0.3"/><color2 r="0.9" g="0.95" b="1"/><scale value="0.2"/>
+    </background>
+    <environment value="0.9" texture="{image}"><rotate angle="45" z="1"/></environment>
+  </scene>
+  <camera gamma="sRGB">
+    <position x="0" y="-38" z="14"/>
+    <target x="0" y="0" z="3"/>
+    <up x="0" y="0" z="1"/>
+    <fov value="38"/>
+    <width value="{width}"/>
+    <height value="{height}"/>
+  </camera>
+</xml>
+"""

@@ -68,6 +68,10 @@ def _load(name):
     L.orc_render.argtypes = [C.POINTER(abi.SceneDesc), C.POINTER(abi.Camera), C.POINTER(abi.RenderParams),
                              C.POINTER(abi.FrameOut), C.c_int, C.c_int, C.c_int, C.POINTER(Stats)]
     L.orc_resolve_pixel.argtypes = [abi.f32p, C.c_int, abi.u8p]
+    L.orc_texture_eval.argtypes = [C.POINTER(abi.SceneDesc), C.c_int, abi.f32p, abi.f32p]
+    L.orc_texture_eval.restype = None
+    L.orc_environment_eval.argtypes = [C.POINTER(abi.SceneDesc), abi.f32p, abi.f32p]
+    L.orc_environment_eval.restype = None
     u64p = C.POINTER(C.c_uint64)
     L.orc_photons_emit.argtypes = [C.POINTER(abi.SceneDesc), C.POINTER(abi.PhotonParams), C.c_int, C.c_uint64, C.c_uint64,
                                    C.c_void_p, C.c_uint32, u64p, u64p, C.POINTER(Stats)]

@@ -273,3 +273,53 @@ def test_photon_emission_and_scatter_samplers():
                 lobes.add(o.lobe)
                 assert_bits_equal(np.array(list(o.dir) + list(o.mult) + [o.prob], f32), gen[i, m], f"GenerateSample {i} {m}")
     assert lobes == {1, 2, 4}
+
+
+def textured_scene(g, tmp_path):
+    """The textured fixture's scene through our own loader: its XML text and image travel in the fixture."""
+    from raytracer_amd import lib, scenes
+    scenes.write_ppm(str(tmp_path / "tex.ppm"), g["image"])
+    return lib.HostScene.from_string(bytes(g["xml"]).decode(), str(tmp_path))
+
+
+@pytest.mark.parametrize("name", ["image_textured_96x54_s8", "whitted_textured_96x54_b5"])
+def test_textures(name, tmp_path):
+    """Checkerboard and image textures with texture transformations on a material's diffuse colour, the background and
+    the environment: our loader's texture maps against the reference's, texture lookups and EvalEnvironment value for
+    value, and the rendered images (path tracer at HEAD: background only; the snapshot's shader: all three) bit for bit."""
+    g = O.load_golden(name)
+    hs = textured_scene(g, tmp_path)
+    d = hs.desc
+    owners = [(0, 0, d.background_texture), (1, 0, d.environment_texture)] + \
+             [(2, k, d.materials[k].diffuse_texture) for k in range(d.n_materials)]
+    owners = [(kind, idx, t) for kind, idx, t in owners if t > 0]
+    assert [(k, i) for k, i, _ in owners] == [tuple(x) for x in g["scene_tex_owner"]]
+    L = O.lib()
+    for row, (_, _, t) in enumerate(owners):
+        tx = d.textures[t - 1]
+        assert tx.type == g["scene_tex_type"][row]
+        assert_bits_equal(np.array(tx.itm[:], np.float32), g["scene_tex_itm"][row], "texture transformation")
+        if tx.type == abi.RT_TEX_CHECKER:
+            assert_bits_equal(np.array(list(tx.color1) + list(tx.color2), np.float32), g["scene_tex_colors"][row], "checker colours")
+        else:
+            assert (tx.width, tx.height) == tuple(g["scene_tex_size"][row])
+            px = np.ctypeslib.as_array(tx.pixels, shape=(tx.height, tx.width, 3))
+            assert np.array_equal(px, g[f"scene_tex{row}_pixels"])
+        got = np.zeros((256, 3), np.float32)
+        for q, uvw in enumerate(g["scene_tex_kat_uvw"][row]):
+            L.orc_texture_eval(C.byref(d), t, uvw.copy().ctypes.data_as(abi.f32p), got[q].ctypes.data_as(abi.f32p))
+        assert_bits_equal(got, g["scene_tex_kat_rgb"][row], f"texture {row} lookups")
+    env = np.zeros((256, 3), np.float32)
+    for q, dirv in enumerate(g["scene_env_kat_dir"]):
+        L.orc_environment_eval(C.byref(d), dirv.copy().ctypes.data_as(abi.f32p), env[q].ctypes.data_as(abi.f32p))
+    assert_bits_equal(env, g["scene_env_kat_rgb"], "EvalEnvironment")
+    seed, mn, mx, w, h = [int(x) for x in g["params"][:5]]
+    kw = dict(seed=seed, min_spp=mn, max_spp=mx, delta_max=float(g["delta"]))
+    if name.startswith("whitted"):
+        kw.update(mode=abi.RT_MODE_WHITTED, max_bounces=int(g["params"][5]))
+    fr = O.render(hs, abi.default_params(**kw), w, h)
+    assert np.array_equal(fr.object_id, g["object_id"]), "primary-hit ids"
+    assert_bits_equal(fr.z, g["z"], "z-buffer")
+    assert_bits_equal(fr.linear, g["linear"], "linear radiance")
+    assert np.array_equal(fr.rgb, g["rgb"]), "8-bit image"
+    assert (g["object_id"] == -1).mean() > 0.05  # the background is in the picture
