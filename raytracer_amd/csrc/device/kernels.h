@@ -150,7 +150,7 @@ struct WorkQueue {
 #define RT_PATHS_MIN_WAVES 6 // waves per SIMD the register allocator must leave room for
 #endif
 
-template <bool COUNT, int LEVELS>
+template <bool COUNT, int LEVELS, bool TEXBG>
 __global__ __launch_bounds__(kBlock, RT_PATHS_MIN_WAVES) void k_paths(DScene S, DFrame F, const float *__restrict__ halton,
                                                   const int32_t *__restrict__ active, uint64_t n_items, int k0, int nk,
                                                   float4 *__restrict__ sbuf, FramePlanes out, DCounters *ctr,
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(kBlock, RT_PATHS_MIN_WAVES) void k_paths(DScene S, 
         }
         pt.tock(4);
         if (alive) {
-            if (!path_step<COUNT, LEVELS>(S, F, ps, st, pt, tl, &fz, &fid)) {
+            if (!path_step<COUNT, LEVELS, TEXBG>(S, F, ps, st, pt, tl, &fz, &fid)) {
                 if (k == 0) {
                     if (out.z) out.z[pix] = fz;
                     if (out.object_id) out.object_id[pix] = fid;

@@ -176,16 +176,21 @@ void fill_frame(const rt_ctx *ctx, const rt_render_params *p, DFrame &F)
     F.gather_radius = p->gather_radius;
 }
 
-const void *paths_kernel(bool counting, int ray_levels, bool lockstep)
+template <bool TEXBG> const void *paths_kernel_lockstep(bool counting, int ray_levels)
+{
+    if (ray_levels <= 1) return counting ? (const void *)k_paths<true, 1, TEXBG> : (const void *)k_paths<false, 1, TEXBG>;
+    if (ray_levels == 2) return counting ? (const void *)k_paths<true, 2, TEXBG> : (const void *)k_paths<false, 2, TEXBG>;
+    return counting ? (const void *)k_paths<true, 5, TEXBG> : (const void *)k_paths<false, 5, TEXBG>;
+}
+
+const void *paths_kernel(bool counting, int ray_levels, bool lockstep, bool textured_background)
 {
     if (!lockstep) {
         if (ray_levels <= 1) return counting ? (const void *)k_path_sm<true, 1> : (const void *)k_path_sm<false, 1>;
         if (ray_levels == 2) return counting ? (const void *)k_path_sm<true, 2> : (const void *)k_path_sm<false, 2>;
         return counting ? (const void *)k_path_sm<true, 5> : (const void *)k_path_sm<false, 5>;
     }
-    if (ray_levels <= 1) return counting ? (const void *)k_paths<true, 1> : (const void *)k_paths<false, 1>;
-    if (ray_levels == 2) return counting ? (const void *)k_paths<true, 2> : (const void *)k_paths<false, 2>;
-    return counting ? (const void *)k_paths<true, 5> : (const void *)k_paths<false, 5>;
+    return textured_background ? paths_kernel_lockstep<true>(counting, ray_levels) : paths_kernel_lockstep<false>(counting, ray_levels);
 }
 
 const void *whitted_kernel(bool counting, int ray_levels)
@@ -355,8 +360,10 @@ int rt_init(int device, rt_ctx **out)
                           (const void *)k_rays<true, 1, RayListIO>, (const void *)k_rays<true, 2, RayListIO>, (const void *)k_rays<true, 5, RayListIO>,
                           (const void *)k_path_sm<false, 1>, (const void *)k_path_sm<false, 2>, (const void *)k_path_sm<false, 5>,
                           (const void *)k_path_sm<true, 1>, (const void *)k_path_sm<true, 2>, (const void *)k_path_sm<true, 5>,
-                          (const void *)k_paths<false, 1>, (const void *)k_paths<false, 2>, (const void *)k_paths<false, 5>,
-                          (const void *)k_paths<true, 1>, (const void *)k_paths<true, 2>, (const void *)k_paths<true, 5>,
+                          (const void *)k_paths<false, 1, false>, (const void *)k_paths<false, 2, false>, (const void *)k_paths<false, 5, false>,
+                          (const void *)k_paths<true, 1, false>, (const void *)k_paths<true, 2, false>, (const void *)k_paths<true, 5, false>,
+                          (const void *)k_paths<false, 1, true>, (const void *)k_paths<false, 2, true>, (const void *)k_paths<false, 5, true>,
+                          (const void *)k_paths<true, 1, true>, (const void *)k_paths<true, 2, true>, (const void *)k_paths<true, 5, true>,
                           (const void *)k_rays<false, 1, PoolIO>, (const void *)k_rays<false, 2, PoolIO>, (const void *)k_rays<false, 5, PoolIO>,
                           (const void *)k_rays<true, 1, PoolIO>, (const void *)k_rays<true, 2, PoolIO>, (const void *)k_rays<true, 5, PoolIO>,
                           (const void *)k_whitted<false, 1>, (const void *)k_whitted<false, 2>, (const void *)k_whitted<false, 5>,
@@ -692,7 +699,7 @@ int rt_render(rt_ctx *ctx, const rt_render_params *prm, rt_frame_out *out)
                 if (int rc = render_wavefront(ctx, F, act, items, k0, nk, P, lds)) return rc;
             } else {
             // persistent launch: as many workgroups as the chip holds at once (more would only queue up)
-            const void *fn = paths_kernel(ctx->counting, ctx->ray_levels, ctx->use_lockstep);
+            const void *fn = paths_kernel(ctx->counting, ctx->ray_levels, ctx->use_lockstep, ctx->scene.background_texture > 0);
             int per_cu = 1;
             HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kBlock, lds));
             per_cu = std::max(1, std::min(per_cu, 8));
