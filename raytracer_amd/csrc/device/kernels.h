@@ -194,12 +194,6 @@ __global__ __launch_bounds__(kBlock, RT_PATHS_MIN_WAVES) void k_paths(DScene S, 
                 rng_set_sequence(ps.rng, (uint64_t)k + 1, seed);
                 path_begin(ps, camera_ray(F, halton, i, j, k, off));
                 fz = FLT_MAX; fid = -1;
-                if (k == 0 && F.max_bounces <= 0) { // no bounce loop to take the depth / id planes from
-                    Hit h;
-                    Tally<false> none;
-                    const bool hit = trace_closest<false, LEVELS>(S, ps.ray, st, h, none);
-                    fz = h.z; fid = hit ? h.node : -1;
-                }
                 alive = true;
                 ++paths;
             }
@@ -222,6 +216,40 @@ __global__ __launch_bounds__(kBlock, RT_PATHS_MIN_WAVES) void k_paths(DScene S, 
         }
     }
     flush_counters<COUNT>(ctr, pt, tl, paths);
+}
+
+// Zero bounces: tracePath's loop body never runs, so every sample is black; only the depth / id planes need the
+// first sample's camera ray.  A kernel of its own, because the same code as a never-taken branch of k_paths cost
+// the 1M-triangle frame 7 % (a second inlined copy of the scene walk in the register allocator's way).
+template <int LEVELS>
+__global__ __launch_bounds__(kBlock) void k_probe(DScene S, DFrame F, const float *__restrict__ halton,
+                                                  const int32_t *__restrict__ active, uint64_t n_items, int k0, int nk,
+                                                  float4 *__restrict__ sbuf, FramePlanes out, DCounters *ctr)
+{
+    extern __shared__ uint32_t lds[];
+    const LaneStack st = lane_stack(lds, S);
+    uint32_t paths = 0;
+    for (uint64_t item = (uint64_t)blockIdx.x * kBlock + threadIdx.x; item < n_items; item += (uint64_t)gridDim.x * kBlock) {
+        const uint32_t a = (uint32_t)(item / (uint32_t)nk);
+        const int k = k0 + (int)(item - (uint64_t)a * (uint32_t)nk);
+        ++paths;
+        sbuf[item] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (k != 0) continue;
+        const int pix = active[a];
+        const uint64_t seed = pixel_seed(F.seed, (uint64_t)pix);
+        Rng rng;
+        rng_set_sequence(rng, 0, seed);
+        float off[4];
+        off[0] = rng_float(rng); off[1] = rng_float(rng); off[2] = rng_float(rng); off[3] = rng_float(rng);
+        const Ray ray = camera_ray(F, halton, pix % F.width, pix / F.width, 0, off);
+        Hit h;
+        Tally<false> none;
+        const bool hit = trace_closest<false, LEVELS>(S, ray, st, h, none);
+        if (out.z) out.z[pix] = h.z;
+        if (out.object_id) out.object_id[pix] = hit ? h.node : -1;
+    }
+    const uint64_t p = wave_sum(paths);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&ctr->paths, (unsigned long long)p);
 }
 
 // int(float) as x86 cvttss2si does it: NaN and out-of-range give INT_MIN

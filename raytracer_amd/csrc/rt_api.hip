@@ -368,6 +368,7 @@ int rt_init(int device, rt_ctx **out)
                           (const void *)k_rays<true, 1, PoolIO>, (const void *)k_rays<true, 2, PoolIO>, (const void *)k_rays<true, 5, PoolIO>,
                           (const void *)k_whitted<false, 1>, (const void *)k_whitted<false, 2>, (const void *)k_whitted<false, 5>,
                           (const void *)k_whitted<true, 1>, (const void *)k_whitted<true, 2>, (const void *)k_whitted<true, 5>,
+                          (const void *)k_probe<1>, (const void *)k_probe<2>, (const void *)k_probe<5>,
                           (const void *)k_trace, (const void *)k_trace_shadow, (const void *)k_trace_paths})
         (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     for (const void *k : {(const void *)k_photon_paths<false, 1>, (const void *)k_photon_paths<false, 2>, (const void *)k_photon_paths<false, 5>,
@@ -694,6 +695,17 @@ int rt_render(rt_ctx *ctx, const rt_render_params *prm, rt_frame_out *out)
                 DCounters *a_ctr = ctx->d_counters.as<DCounters>();
                 unsigned long long *a_queue = ctx->d_queue.as<unsigned long long>();
                 void *args[] = {&a_scene, &F, &a_hal, &act, &a_items, &a_k0, &a_nk, &a_sbuf, &P, &a_ctr, &a_queue};
+                HIP_TRY(ctx, hipLaunchKernel(fn, grid, dim3(kBlock), args, lds, s));
+            } else if (prm->max_bounces <= 0 && ctx->use_lockstep && !ctx->use_wavefront) {
+                const void *fn = ctx->ray_levels <= 1 ? (const void *)k_probe<1> : ctx->ray_levels == 2 ? (const void *)k_probe<2> : (const void *)k_probe<5>;
+                const dim3 grid((unsigned)std::min<uint64_t>((items + kBlock - 1) / kBlock, ctx->ovf_threads / kBlock));
+                DScene a_scene = ctx->scene;
+                const float *a_hal = ctx->d_halton.as<float>();
+                uint64_t a_items = items;
+                int a_k0 = k0, a_nk = nk;
+                float4 *a_sbuf = ctx->d_sbuf.as<float4>();
+                DCounters *a_ctr = ctx->d_counters.as<DCounters>();
+                void *args[] = {&a_scene, &F, &a_hal, &act, &a_items, &a_k0, &a_nk, &a_sbuf, &P, &a_ctr};
                 HIP_TRY(ctx, hipLaunchKernel(fn, grid, dim3(kBlock), args, lds, s));
             } else if (ctx->use_wavefront) {
                 if (int rc = render_wavefront(ctx, F, act, items, k0, nk, P, lds)) return rc;
