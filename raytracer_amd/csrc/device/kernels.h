@@ -94,7 +94,9 @@ RT_DEV Ray camera_ray(const DFrame &F, const float *halton, int i, int j, int k,
     const float jr = frac_sum(halton[192 + hk], off[3]);
     const float theta = (float)((double)(jt * 2.0f) * M_PI); // float*float, then *double (main.cpp:313)
     const float radius = fsqrt(jr);
-    const V3 lens = mk(radius * F.dof * cosf(theta), radius * F.dof * sinf(theta), 0.0f);
+    float st_, ct_;
+    sincos_2pi(theta, st_, ct_);
+    const V3 lens = mk(radius * F.dof * ct_, radius * F.dof * st_, 0.0f);
     Ray r;
     r.p = cpos + m3_mul(F.cam2world, lens);
     r.d = dest - r.p;

@@ -20,24 +20,6 @@ constexpr double kEightPi = 8.0f * M_PI;
 constexpr double kTwoPi = 2.0f * M_PI;
 RT_DEV float sum3(const float *c) { return c[0] + c[1] + c[2]; }
 
-// sin and cos of x in [0, 2 pi] in double: quadrant reduction against a two-part pi/2, then the
-// classic minimax polynomials on [-pi/4, pi/4].  Errors stay below one ulp of double, which is
-// invisible once the result is narrowed to float.
-RT_DEV void dsincos(double x, double &s, double &c)
-{
-    const double k = __builtin_rint(x * 0.63661977236758134308);
-    const double r = (x - k * 1.57079632673412561417e+00) - k * 6.07710050650619224932e-11;
-    const double z = r * r;
-    const double ps = -1.66666666666666324348e-01 + z * (8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 +
-                      z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10))));
-    const double pc = 4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 +
-                      z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11))));
-    const double sr = r + r * z * ps;
-    const double cr = (1.0 - 0.5 * z) + z * z * pc;
-    const int q = (int)k & 3;
-    s = (q == 0) ? sr : (q == 1) ? cr : (q == 2) ? -sr : -cr;
-    c = (q == 0) ? cr : (q == 1) ? -sr : (q == 2) ? -cr : sr;
-}
 // (float)(a * cos(t)), (float)(a * sin(t)) with a, t float: the product is formed in double
 RT_DEV void scaled_sincos(float a, float t, float &as, float &ac)
 {

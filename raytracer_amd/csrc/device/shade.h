@@ -43,8 +43,10 @@ RT_DEV void light_generate(const rt_light &l, V3 P, Rng &rng, Sample &o)
     const float cosT = 1.0f - r1 + r1 * cosMax;
     const float sinT = fsqrt(1.0f - (cosT * cosT));
     const float phi = 2.0f * kPi * rng_float(rng);
-    const float x = sinT * cosf(phi);
-    const float y = sinT * sinf(phi);
+    float sp, cp;
+    sincos_2pi(phi, sp, cp);
+    const float x = sinT * cp;
+    const float y = sinT * sp;
     const float z = cosT;
     V3 u, v;
     orthonormals(toC, u, v);
@@ -103,8 +105,10 @@ RT_DEV bool mtl_generate(const rt_material &m, const Surface &s, Rng &rng, Sampl
         o.lobe = LOBE_DIFFUSE;
         const float r = fsqrt(rng_float(rng));
         const float theta = 2.0f * kPi * rng_float(rng);
-        const float x = r * cosf(theta);
-        const float y = r * sinf(theta);
+        float st_, ct_;
+        sincos_2pi(theta, st_, ct_);
+        const float x = r * ct_;
+        const float y = r * st_;
         const float z = fsqrt(std_max(0.0f, 1.0f - x * x - y * y));
         V3 u, v;
         orthonormals(Ns, u, v);
@@ -121,8 +125,10 @@ RT_DEV bool mtl_generate(const rt_material &m, const Surface &s, Rng &rng, Sampl
         const float phi = 2.0f * kPi * rng_float(rng);
         const float cosT = powf(1.0f - rng_float(rng), 1.0f / (alpha + 1.0f));
         const float sinT = fsqrt(1.0f - cosT * cosT);
-        const float x = sinT * cosf(phi);
-        const float y = sinT * sinf(phi);
+        float sp, cp;
+        sincos_2pi(phi, sp, cp);
+        const float x = sinT * cp;
+        const float y = sinT * sp;
         V3 u, v;
         orthonormals(Ns, u, v);
         const V3 h = (u * x + v * y) + Ns * cosT;
@@ -147,8 +153,10 @@ RT_DEV bool mtl_generate(const rt_material &m, const Surface &s, Rng &rng, Sampl
         const float phi = 2.0f * kPi * rng_float(rng);
         const float cosT = powf(1.0f - rng_float(rng), 1.0f / (alpha + 1.0f));
         const float sinT = fsqrt(1.0f - cosT * cosT);
-        const float x = sinT * cosf(phi);
-        const float y = sinT * sinf(phi);
+        float sp, cp;
+        sincos_2pi(phi, sp, cp);
+        const float x = sinT * cp;
+        const float y = sinT * sp;
         V3 u, v;
         orthonormals(N, u, v);
         const V3 h = (u * x + v * y) + N * cosT;

@@ -199,7 +199,9 @@ RT_DEV bool bvh_box_exact(V3 p, V3 inv, float t_max, f4 b0, f4 b1, float &dist)
 }
 RT_DEV bool bvh_box(bool exact, V3 p, V3 inv, float t_max, f4 b0, f4 b1, float &dist)
 {
+#ifndef RT_ABLATE_EXACT
     if (__builtin_expect(exact, 0)) return bvh_box_exact(p, inv, t_max, b0, b1, dist);
+#endif
     return bvh_box_fast(p, inv, t_max, b0, b1, dist);
 }
 // entry distance alone (same operations, same bits)

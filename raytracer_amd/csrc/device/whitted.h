@@ -329,7 +329,9 @@ __global__ __launch_bounds__(kBlock, 4) void k_whitted(DScene S, DFrame F, const
                     const float sinTheta = fsqrt(1.0f - cosTheta * cosTheta);
                     V3 u, v;
                     orthonormals(cur.n, u, v);
-                    child_dir = whitted_frame(u, v, cur.n, sinTheta * cosf(phi), sinTheta * sinf(phi), cosTheta);
+                    float sp_, cp_;
+                    sincos_2pi(phi, sp_, cp_);
+                    child_dir = whitted_frame(u, v, cur.n, sinTheta * cp_, sinTheta * sp_, cosTheta);
                     child = COMB_MC;
                 }
             } else if (stage == STG_REFL) { // glossy reflection (p12 materials.cpp:106-133)
@@ -342,7 +344,9 @@ __global__ __launch_bounds__(kBlock, 4) void k_whitted(DScene S, DFrame F, const
                     const float sinTheta = fsqrt(1.0f - cosTheta * cosTheta);
                     V3 u, v;
                     orthonormals(cur.n, u, v);
-                    const V3 h = whitted_frame(u, v, cur.n, sinTheta * cosf(phi), sinTheta * sinf(phi), cosTheta);
+                    float sp_, cp_;
+                    sincos_2pi(phi, sp_, cp_);
+                    const V3 h = whitted_frame(u, v, cur.n, sinTheta * cp_, sinTheta * sp_, cosTheta);
                     const V3 rd = (h * 2.0f) * dot(cur.v, h) - cur.v;
                     if (dot(rd, cur.n) > 0.0f) { child_dir = rd; child = COMB_REFL; }
                 }
@@ -356,7 +360,9 @@ __global__ __launch_bounds__(kBlock, 4) void k_whitted(DScene S, DFrame F, const
                 const float phi = (float)(kTwoPi * frac_sum(halton[ps_h], phiOffset));
                 const float cosTheta = powf(frac_sum(halton[64 + ps_h], thetaOffset), 1.0f / (m.glossiness + 1.0f));
                 const float sinTheta = fsqrt(1.0f - cosTheta * cosTheta);
-                const V3 h = whitted_frame(u, v, N, sinTheta * cosf(phi), sinTheta * sinf(phi), cosTheta);
+                float sp_, cp_;
+                sincos_2pi(phi, sp_, cp_);
+                const V3 h = whitted_frame(u, v, N, sinTheta * cp_, sinTheta * sp_, cosTheta);
                 cur.h = h;
                 const float viewDotH = dot(cur.v, h);
                 const float ratio = front ? 1.0f / m.ior : m.ior;
