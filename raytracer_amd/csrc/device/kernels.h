@@ -67,6 +67,12 @@ RT_DEV void flush_counters(DCounters *ctr, const PathTally &pt, const Tally<COUN
         for (int i = 0; i < 16; ++i) atomicAdd(&ctr->phase[i], pt.ph[i]); // lane 0's clocks stand for the wave
 #endif
     }
+#ifdef RT_PROFILE_LANES
+    for (int i = 0; i < 8; ++i) {
+        const uint64_t wv = wave_sum(tl.wave[i]), ln = wave_sum(tl.lanes[i]);
+        if ((threadIdx.x & 63) == 0) { atomicAdd(&ctr->phase[i], (unsigned long long)wv); atomicAdd(&ctr->phase[8 + i], (unsigned long long)ln); }
+    }
+#endif
 }
 
 RT_DEV uint64_t pixel_seed(uint64_t frame, uint64_t pix) { return frame + pix * 0x9E3779B97F4A7C15ULL; }
@@ -148,6 +154,9 @@ struct WorkQueue {
     }
 };
 
+#ifndef RT_RESUMABLE_WALKS
+#define RT_RESUMABLE_WALKS 0 // 1: closest-hit walks of k_paths can be put down and taken up again (WalkState); measured slower, see trace.h
+#endif
 #ifndef RT_PATHS_MIN_WAVES
 #define RT_PATHS_MIN_WAVES 6 // waves per SIMD the register allocator must leave room for
 #endif
@@ -171,6 +180,9 @@ __global__ __launch_bounds__(kBlock, RT_PATHS_MIN_WAVES) void k_paths(DScene S, 
     int pix = 0, k = 0;
     float fz = FLT_MAX; int fid = -1;
     PathState ps;
+#if RT_RESUMABLE_WALKS
+    WalkState ws;
+#endif
     path_begin(ps, Ray{mk(0, 0, 0), mk(0, 0, 1)});
     ps.rng.state = 0; ps.rng.inc = 1;
 
@@ -207,7 +219,11 @@ __global__ __launch_bounds__(kBlock, RT_PATHS_MIN_WAVES) void k_paths(DScene S, 
         }
         pt.tock(4);
         if (alive) {
+#if RT_RESUMABLE_WALKS
+            if (!path_step<COUNT, LEVELS, TEXBG, true>(S, F, ps, st, pt, tl, &fz, &fid, &ws)) {
+#else
             if (!path_step<COUNT, LEVELS, TEXBG>(S, F, ps, st, pt, tl, &fz, &fid)) {
+#endif
                 if (k == 0) {
                     if (out.z) out.z[pix] = fz;
                     if (out.object_id) out.object_id[pix] = fid;
