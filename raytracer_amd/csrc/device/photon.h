@@ -305,22 +305,54 @@ constexpr uint32_t kFarIsLow = 0x80000000u, kFarDone = 0x40000000u;
 // Heap of one lane: 130 entries of (dist2, node), entry e at heap[e]; entry 0 is unused (dist2[0] lives in a
 // register), entry 129 is padding so that the pair (j, j+1) can always be read with one 16-byte load.
 // A lane's entries are contiguous in global memory (not interleaved with other lanes' as private arrays
-// are): a sift step is one 16-byte load of both children and one 8-byte store, and the top of the heap,
-// which every replacement goes through, stays on one cache line.
+// are): a sift step is one 16-byte load of both children and one 8-byte store.  Entries 1..kHeapLds (the top
+// levels, which every replacement goes through) live in LDS instead, behind the lanes' stacks, as
+// top[entry - 1][thread]: the heaps of the lanes in flight (1 KB each, 400 MB) fit no cache, and the lookup is
+// bound by the memory traffic of its own heap.
+#ifndef RT_HEAP_LDS_ENTRIES
+#define RT_HEAP_LDS_ENTRIES 7 // 0, 1, 3, 7 or 15: whole heap levels
+#endif
+constexpr uint32_t kHeapLds = RT_HEAP_LDS_ENTRIES;
+static_assert(kHeapLds == 0 || kHeapLds == 1 || kHeapLds == 3 || kHeapLds == 7 || kHeapLds == 15, "whole levels of the heap");
 constexpr uint32_t kHeapStride = 130;
-RT_DEV u32x2 *lane_heap(const DScene &S) { return (u32x2 *)S.gather_heaps + ((size_t)blockIdx.x * kBlock + threadIdx.x) * kHeapStride; }
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+struct LaneHeap {
+    typedef RT_GLOBAL_AS u32x2 *GH2;
+    typedef RT_GLOBAL_AS u32x4 *GH4;
+    GH2 g;    // entry e at g[e]
+    u32x2 *l; // entry e <= kHeapLds at l[(e - 1) * kStackStride]
+    RT_DEV u32x2 get(int e) const { return (uint32_t)e <= kHeapLds ? l[(uint32_t)(e - 1) * kStackStride] : g[e]; }
+    RT_DEV void put(int e, u32x2 v) const
+    {
+        if ((uint32_t)e <= kHeapLds) l[(uint32_t)(e - 1) * kStackStride] = v;
+        else g[e] = v;
+    }
+    // entries j and j + 1, j even: both on the same side of the boundary (kHeapLds is odd)
+    RT_DEV u32x4 pair(int j) const
+    {
+        if ((uint32_t)j < kHeapLds) {
+            const u32x2 a = l[(uint32_t)(j - 1) * kStackStride], b = l[(uint32_t)j * kStackStride];
+            return u32x4{a.x, a.y, b.x, b.y};
+        }
+        return *(GH4)&g[j];
+    }
+};
+// lds: the workgroup's dynamic LDS, the lanes' stacks first (S.lds_levels entries per thread)
+RT_DEV LaneHeap lane_heap(const DScene &S, uint32_t *lds)
+{
+    LaneHeap h;
+    h.g = (LaneHeap::GH2)((u32x2 *)S.gather_heaps + ((size_t)blockIdx.x * kBlock + threadIdx.x) * kHeapStride);
+    h.l = (u32x2 *)lds + (size_t)S.lds_levels * kStackStride + threadIdx.x;
+    return h;
+}
 
 template <bool COUNT>
 RT_DEV V3 photon_irradiance(const rt_photon *tree0, uint32_t n, V3 pos, V3 normal, float radius, LaneStack st,
-                            u32x2 *heap, uint32_t &visits)
+                            const LaneHeap H, uint32_t &visits)
 {
     if (n == 0) return mk(0, 0, 0);
     const GF4 tree = (GF4)(const void *)tree0 - 2; // node i = tree[2 i], tree[2 i + 1]
     const int half = (int)n / 2 - 1;               // nodes below this index are treated as internal (src/photonmap.h:197,346)
-    typedef RT_GLOBAL_AS u32x2 *GH2;
-    typedef RT_GLOBAL_AS u32x4 *GH4;
-    const GH2 H = (GH2)heap;
     int found = 0;
     float lim = radius * radius; // dist2[0]
     int sp = 0;
@@ -349,41 +381,41 @@ RT_DEV V3 photon_irradiance(const rt_photon *tree0, uint32_t n, V3 pos, V3 norma
                 if (dist2 < lim && !(dot(mk(q1.x, q1.y, q1.z), normal) >= 0.0f)) {
                     if (found < kGatherK) {
                         ++found;
-                        H[found] = u32x2{__float_as_uint(dist2), node};
+                        H.put(found, u32x2{__float_as_uint(dist2), node});
                         if (found == kGatherK) { // build the max-heap
                             const int half_found = found >> 1;
                             for (int k = half_found; k >= 1; --k) {
                                 int parent = k;
-                                const u32x2 t = H[k];
+                                const u32x2 t = H.get(k);
                                 const float td2 = __uint_as_float(t.x);
                                 while (parent <= half_found) {
                                     int j = parent + parent;
-                                    const u32x4 c = *(GH4)&H[j];
+                                    const u32x4 c = H.pair(j);
                                     float dj = __uint_as_float(c.x);
                                     uint32_t ij = c.y;
                                     if (j < found && dj < __uint_as_float(c.z)) { ++j; dj = __uint_as_float(c.z); ij = c.w; }
                                     if (td2 >= dj) break;
-                                    H[parent] = u32x2{__float_as_uint(dj), ij};
+                                    H.put(parent, u32x2{__float_as_uint(dj), ij});
                                     parent = j;
                                 }
-                                H[parent] = t;
+                                H.put(parent, t);
                             }
                         }
                     } else { // replace the farthest
                         int parent = 1, j = 2;
                         float top = dist2; // what ends up in entry 1
                         while (j <= found) {
-                            const u32x4 c = *(GH4)&H[j];
+                            const u32x4 c = H.pair(j);
                             float dj = __uint_as_float(c.x);
                             uint32_t ij = c.y;
                             if (j < found && dj < __uint_as_float(c.z)) { ++j; dj = __uint_as_float(c.z); ij = c.w; }
                             if (dist2 > dj) break;
-                            H[parent] = u32x2{__float_as_uint(dj), ij};
+                            H.put(parent, u32x2{__float_as_uint(dj), ij});
                             if (parent == 1) top = dj;
                             parent = j;
                             j <<= 1;
                         }
-                        H[parent] = u32x2{__float_as_uint(dist2), node};
+                        H.put(parent, u32x2{__float_as_uint(dist2), node});
                         lim = top;
                     }
                 }
@@ -410,7 +442,7 @@ RT_DEV V3 photon_irradiance(const rt_photon *tree0, uint32_t n, V3 pos, V3 norma
     }
     V3 sum = mk(0, 0, 0);
     for (int i = 1; i <= found; ++i) {
-        const uint32_t id = H[i].y;
+        const uint32_t id = H.get(i).y;
         const f4 q0 = tree[2 * id], q1 = tree[2 * id + 1];
         const uint32_t rgb = __float_as_uint(q1.w);
         const V3 col = mk((float)(rgb & 255u) / 255.0f, (float)((rgb >> 8) & 255u) / 255.0f, (float)((rgb >> 16) & 255u) / 255.0f);
@@ -430,7 +462,7 @@ __global__ __launch_bounds__(kBlock) void k_photon_irradiance(DScene S, const rt
     extern __shared__ uint32_t lds[];
     const LaneStack st = lane_stack(lds, S);
     uint32_t visits = 0, gathers = 0;
-    u32x2 *heap = lane_heap(S);
+    const LaneHeap heap = lane_heap(S, lds);
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         const V3 e = photon_irradiance<true>(tree, n_photons, ld3(pos3 + (size_t)i * 3), ld3(nrm3 + (size_t)i * 3), radius, st, heap, visits);
         out3[(size_t)i * 3] = e.x; out3[(size_t)i * 3 + 1] = e.y; out3[(size_t)i * 3 + 2] = e.z;

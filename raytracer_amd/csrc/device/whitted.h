@@ -19,7 +19,7 @@
 namespace rtd {
 
 #ifndef RT_GATHER_QUORUM
-#define RT_GATHER_QUORUM 32
+#define RT_GATHER_QUORUM 64 // measured on the photon-box frame: 16 / 32 / 48 / 64 lanes -> 4.04 / 3.56 / 3.11 / 2.99 s
 #endif
 constexpr int kGatherQuorum = RT_GATHER_QUORUM; // parked lanes that start a round of photon lookups
 constexpr int kMaxWhittedBounces = 8; // the snapshot compiles in 5; the tree grows as 3^bounces
@@ -156,13 +156,13 @@ __global__ __launch_bounds__(kBlock, 4) void k_whitted(DScene S, DFrame F, const
         }
 
         // Photon lookups are long (hundreds of kd-tree nodes) next to a ray of this kind of scene, and lanes reach
-        // them at different times: parked lanes wait until half the wave is parked or nothing else is left to do,
+        // them at different times: parked lanes wait until the whole wave is parked or nothing else is left to do,
         // then gather together.
         const uint64_t parked = __ballot(state == W_GATHER);
         if (parked != 0 && (__popcll(parked) >= kGatherQuorum || !__any(state == W_TRACE || state == W_SHADOW))) {
             if (state == W_GATHER) {
                 const V3 kd = cur.kd * kInvPiF;
-                u32x2 *heap = lane_heap(S);
+                const LaneHeap heap = lane_heap(S, lds);
                 if (pm & (RT_PM_DIRECT | RT_PM_INDIRECT)) {
                     cur.final = cur.final + kd * photon_irradiance<COUNT>(S.pmap[0], S.pmap_n[0], cur.p, cur.n, F.gather_radius, st, heap, visits);
                     ++gathers;

@@ -215,6 +215,8 @@ const void *wf_trace_kernel(bool counting, int ray_levels)
 }
 
 size_t stack_lds_bytes(const DScene &S) { return (size_t)S.lds_levels * kBlock * 8; }
+// kernels that look photons up keep the top of every lane's heap behind the stacks
+size_t gather_lds_bytes(const DScene &S) { return stack_lds_bytes(S) + (size_t)kHeapLds * kBlock * 8; }
 
 } // namespace
 
@@ -659,7 +661,8 @@ int rt_render(rt_ctx *ctx, const rt_render_params *prm, rt_frame_out *out)
     }
 
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters.p, 0, sizeof(DCounters), s));
-    const size_t lds = stack_lds_bytes(ctx->scene);
+    const bool gathers = prm->mode == RT_MODE_WHITTED && prm->photon_flags != 0;
+    const size_t lds = gathers ? gather_lds_bytes(ctx->scene) : stack_lds_bytes(ctx->scene);
     double trace_ms = 0.0;
     uint32_t launches = 0;
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, s));
@@ -960,7 +963,8 @@ int ensure_stack_levels(rt_ctx *ctx, int levels)
     if (levels <= S.stack_levels) return RT_OK;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     S.stack_levels = levels;
-    S.lds_levels = std::min(S.stack_levels, ctx->lds_levels_max);
+    // four workgroups of the lookup kernels share a CU's 160 KiB: 20 eight-byte entries per thread, the heap tops included
+    S.lds_levels = std::min(S.stack_levels, std::min(ctx->lds_levels_max, 19 - (int)kHeapLds));
     const size_t ovf_levels = (size_t)(S.stack_levels - S.lds_levels);
     HIP_TRY(ctx, ctx->d_stack_ovf.reserve(std::max<size_t>(1, ovf_levels) * ctx->ovf_threads * sizeof(uint2) * rt_ctx::kMaxPools));
     S.stack_overflow = ctx->d_stack_ovf.as<uint2>();
@@ -1182,7 +1186,7 @@ int rt_photons_irradiance(rt_ctx *ctx, int which, const float *pos3, const float
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_q_aux.p, normal3, (size_t)n * 12, hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters.p, 0, sizeof(DCounters), s));
     HIP_TRY(ctx, hipEventRecord(ctx->evk0, s));
-    hipLaunchKernelGGL(k_photon_irradiance, batch_grid(ctx, n), dim3(kBlock), stack_lds_bytes(ctx->scene), s, ctx->scene,
+    hipLaunchKernelGGL(k_photon_irradiance, batch_grid(ctx, n), dim3(kBlock), gather_lds_bytes(ctx->scene), s, ctx->scene,
                        ctx->d_pmap[which].as<rt_photon>(), ctx->pmap_n[which], ctx->d_q_in.as<float>(), ctx->d_q_aux.as<float>(), n, radius,
                        ctx->d_q_out.as<float>(), ctx->d_counters.as<DCounters>());
     HIP_TRY(ctx, hipGetLastError());
