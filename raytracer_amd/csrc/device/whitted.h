@@ -21,6 +21,9 @@ namespace rtd {
 #ifndef RT_GATHER_QUORUM
 #define RT_GATHER_QUORUM 64 // measured on the photon-box frame: 16 / 32 / 48 / 64 lanes -> 4.04 / 3.56 / 3.11 / 2.99 s
 #endif
+#ifndef RT_WHITTED_MIN_WAVES
+#define RT_WHITTED_MIN_WAVES 4 // waves per SIMD the register allocator must leave room for
+#endif
 constexpr int kGatherQuorum = RT_GATHER_QUORUM; // parked lanes that start a round of photon lookups
 constexpr int kMaxWhittedBounces = 8; // the snapshot compiles in 5; the tree grows as 3^bounces
 
@@ -93,7 +96,7 @@ RT_DEV float whitted_fresnel(float ior, float viewDotH)
 }
 
 template <bool COUNT, int LEVELS>
-__global__ __launch_bounds__(kBlock, 4) void k_whitted(DScene S, DFrame F, const float *__restrict__ halton,
+__global__ __launch_bounds__(kBlock, RT_WHITTED_MIN_WAVES) void k_whitted(DScene S, DFrame F, const float *__restrict__ halton,
                                                        const int32_t *__restrict__ active, uint64_t n_items, int k0, int nk,
                                                        float4 *__restrict__ sbuf, FramePlanes out, DCounters *ctr,
                                                        unsigned long long *queue)
