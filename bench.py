@@ -188,6 +188,9 @@ def main():
     ap.add_argument("--workload", default="mesh_1m_1080p_64spp", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--max-bounces", type=int, default=None, help="development only: the headline number uses 50")
+    ap.add_argument("--tile-size", type=int, default=None, help="development only: side of the tiles dealt to the ranks")
+    ap.add_argument("--shard", default=None, metavar="R/W",
+                    help="development only: one GPU renders the tiles rank R of W would get (no gather): per-rank time of a W-GPU run")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -207,8 +210,12 @@ def main():
     ctx = lib.Context(local)
     ctx.upload(hs.desc)
     ctx.set_camera(hs.camera)
-    prm = abi.default_params(mode=mode, min_spp=spp_min, max_spp=spp_max, seed=7, tile_rank=rank, tile_world=world,
+    tile_rank, tile_world = (int(x) for x in args.shard.split("/")) if args.shard else (rank, world)
+    headline = headline and not args.shard
+    prm = abi.default_params(mode=mode, min_spp=spp_min, max_spp=spp_max, seed=7, tile_rank=tile_rank, tile_world=tile_world,
                              max_bounces=bounces, photon_flags=pp.flags if pp else 0, gather_radius=3.0)
+    if args.tile_size:
+        prm.tile_size = args.tile_size
     fb = FrameBuffers(w, h, dev)
     gather = FrameGather(w, h, prm.tile_size, rank, world, dev)
     filler = PhotonFill(ctx, rank, world, dev) if pp else None
