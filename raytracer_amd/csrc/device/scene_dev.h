@@ -21,8 +21,9 @@ struct DNode {
     int32_t depth;        // root = 0
     int32_t has_children;
     int32_t chain[kMaxSceneDepth]; // ancestors root-first, chain[depth] = this node
-    int32_t pad[4];
-}; // 160 bytes
+    float wbox[6];        // world-space box around the node's own object, padded: min xyz, max xyz (-/+FLT_MAX: unknown)
+    int32_t pad[2];
+}; // 176 bytes
 
 // One triangle mesh.
 //   bvh  : 32-byte nodes, two float4 each: (min.x, max.x, min.y, max.y) (min.z, max.z, data, 0);

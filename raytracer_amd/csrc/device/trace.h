@@ -515,24 +515,43 @@ template <int LEVELS> struct RayLevels {
     RT_DEV void init(Ray v) { r0 = r1 = r2 = r3 = r4 = v; }
 };
 
+// Does the ray reach the node's world-space box before t_max?  Used only to skip work (CULL): the boxes are padded,
+// so approximate reciprocals are good enough, and a NaN anywhere says "reaches".
+RT_DEV V3 cull_inverse(V3 d) { return mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z)); }
+RT_DEV bool reaches_box(const float *b, V3 p, V3 inv, float t_max)
+{
+    const float x1 = (b[0] - p.x) * inv.x, x2 = (b[3] - p.x) * inv.x;
+    const float y1 = (b[1] - p.y) * inv.y, y2 = (b[4] - p.y) * inv.y;
+    const float z1 = (b[2] - p.z) * inv.z, z2 = (b[5] - p.z) * inv.z;
+    const float tNear = vmax(vmax3(vmin(x1, x2), vmin(y1, y2), vmin(z1, z2)), 0.0f);
+    const float tFar = vmin(vmin3(vmax(x1, x2), vmax(y1, y2), vmax(z1, z2)), t_max);
+    return !(tNear > tFar);
+}
+
 // shootRay + shootRayAtLights (src/main.cpp:16-70,115-120).  The winner is the
 // first hit in depth-first order with the smallest z (strict <), which is what
 // the reference's per-level comparisons select.
-template <bool COUNT, int LEVELS>
+// With CULL an object none of the wave's rays can reach (its world-space box is missed, or lies behind the closest
+// hit so far: t is the same in every node's space) is skipped by the whole wave.
+template <bool COUNT, int LEVELS, bool CULL = false>
 RT_DEV bool trace_closest(const DScene &S, Ray ray, LaneStack st, Hit &h, Tally<COUNT> &tl)
 {
     h.z = FLT_MAX; h.node = -1; h.front = 1; h.face = 0; h.u = 0; h.v = 0;
     RayLevels<LEVELS> lv;
     lv.init(ray);
+    const V3 winv = CULL ? cull_inverse(ray.d) : ray.d;
     const int n = S.n_nodes;
     for (int i = 0; i < n; ++i) {
         const DNode &nd = S.nodes[i];
         const int d = nd.depth;
+        // one vote per node: does any ray of the wave reach the object's box?
+        const bool skip = CULL && (nd.prim == RT_PRIM_NONE || !__any(reaches_box(nd.wbox, ray.p, winv, h.z)));
+        if (skip && !nd.has_children) continue;
         const Ray parent = (d == 0) ? ray : lv.get(d - 1);
         const Ray lr = to_node(nd, parent);
         if (nd.has_children) lv.set(d, lr);
         const int prim = nd.prim;
-        if (prim == RT_PRIM_NONE) continue;
+        if (prim == RT_PRIM_NONE || skip) continue;
         float t = 0; int front = 1; bool ok = false;
         uint32_t face = 0; float u = 0, v = 0;
         if (prim == RT_PRIM_SPHERE) ok = sphere_t(lr, t, front);
@@ -673,20 +692,23 @@ RT_DEV void finish_hit(const DScene &S, Ray ray, Hit &h, bool want_uvw)
 }
 
 // shootShadowRay (src/main.cpp:72-89,122-125): any hit with t < t_max
-template <bool COUNT, int LEVELS>
+template <bool COUNT, int LEVELS, bool CULL = false>
 RT_DEV bool trace_shadow(const DScene &S, Ray ray, float t_max, LaneStack st, Tally<COUNT> &tl)
 {
     RayLevels<LEVELS> lv;
     lv.init(ray);
+    const V3 winv = CULL ? cull_inverse(ray.d) : ray.d;
     const int n = S.n_nodes;
     for (int i = 0; i < n; ++i) {
         const DNode &nd = S.nodes[i];
         const int d = nd.depth;
+        const bool skip = CULL && (nd.prim == RT_PRIM_NONE || !__any(reaches_box(nd.wbox, ray.p, winv, t_max)));
+        if (skip && !nd.has_children) continue;
         const Ray parent = (d == 0) ? ray : lv.get(d - 1);
         const Ray lr = to_node(nd, parent);
         if (nd.has_children) lv.set(d, lr);
         const int prim = nd.prim;
-        if (prim == RT_PRIM_NONE) continue;
+        if (prim == RT_PRIM_NONE || skip) continue;
         bool occ;
         if (prim == RT_PRIM_SPHERE) occ = sphere_shadow(lr, t_max);
         else if (prim == RT_PRIM_PLANE) occ = plane_shadow(lr, t_max);

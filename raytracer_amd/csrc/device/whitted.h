@@ -24,6 +24,10 @@ namespace rtd {
 #ifndef RT_WHITTED_MIN_WAVES
 #define RT_WHITTED_MIN_WAVES 4 // waves per SIMD the register allocator must leave room for
 #endif
+#ifndef RT_WHITTED_CULL
+#define RT_WHITTED_CULL 1 // skip objects whose world-space box no ray of the wave reaches
+#endif
+constexpr bool kWhittedCull = RT_WHITTED_CULL != 0;
 constexpr int kGatherQuorum = RT_GATHER_QUORUM; // parked lanes that start a round of photon lookups
 constexpr int kMaxWhittedBounces = 8; // the snapshot compiles in 5; the tree grows as 3^bounces
 
@@ -181,7 +185,7 @@ __global__ __launch_bounds__(kBlock, RT_WHITTED_MIN_WAVES) void k_whitted(DScene
         if (state == W_TRACE) { // camera ray (depth 0) or TraceSecondaryRay
             Hit h;
             ++pt.closest;
-            const bool hit = trace_closest<COUNT, LEVELS>(S, ray, st, h, tl);
+            const bool hit = trace_closest<COUNT, LEVELS, kWhittedCull>(S, ray, st, h, tl);
             if (depth == 0) { fz = h.z; fid = hit ? h.node : -1; }
             if (!hit) {
                 if (depth == 0) { // p12 main.cpp:224-226: the background at the sample's un-jittered Halton point
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(kBlock, RT_WHITTED_MIN_WAVES) void k_whitted(DScene
             }
         } else if (state == W_SHADOW) {
             ++pt.shadow;
-            const bool occluded = trace_shadow<COUNT, LEVELS>(S, ray, tmax, st, tl);
+            const bool occluded = trace_shadow<COUNT, LEVELS, kWhittedCull>(S, ray, tmax, st, tl);
             const rt_light &L = S.lights[l];
             const rt_material &m = S.materials[mtl];
             if (L.type == RT_LIGHT_DIRECT) {

@@ -528,6 +528,38 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc)
         HIP_TRY(ctx, upload(m.vn, (size_t)m.nvn * 12, (const void **)&d.vn));
         HIP_TRY(ctx, upload(m.vt, (size_t)m.nvt * 12, (const void **)&d.vt));
     }
+    // ---- world-space boxes of the object nodes: rays that miss a node's box need not be taken into its space.
+    // The reference tests every ray against every object (src/main.cpp:16-89); skipping one whose box the ray misses
+    // changes no answer as long as the box is conservative, hence the padding (node matrices and their inverses are
+    // single precision and agree to a few ulp only).
+    for (uint32_t i = 0; i < nn; ++i) {
+        DNode &d = nodes[i];
+        for (int a = 0; a < 3; ++a) { d.wbox[a] = -FLT_MAX; d.wbox[3 + a] = FLT_MAX; }
+        double lo[3] = {-1, -1, -1}, hi[3] = {1, 1, 1}; // unit sphere; unit square in z = 0
+        if (d.prim == RT_PRIM_PLANE) lo[2] = hi[2] = 0;
+        else if (d.prim == RT_PRIM_MESH) {
+            const rt_bvh_node &root = sc->meshes[d.mesh].bvh_nodes[1];
+            for (int a = 0; a < 3; ++a) { lo[a] = root.bounds[a]; hi[a] = root.bounds[3 + a]; }
+        } else if (d.prim != RT_PRIM_SPHERE) continue;
+        double wlo[3] = {1e300, 1e300, 1e300}, whi[3] = {-1e300, -1e300, -1e300};
+        bool finite = true;
+        for (int c = 0; c < 8; ++c) {
+            double q[3] = {(c & 1) ? hi[0] : lo[0], (c & 2) ? hi[1] : lo[1], (c & 4) ? hi[2] : lo[2]};
+            for (int k = d.depth; k >= 0; --k) { // node space -> world, through the ancestors' transformations
+                const float *m = nodes[d.chain[k]].tm;
+                const double x = q[0] * m[0] + q[1] * m[3] + q[2] * m[6] + m[9];
+                const double y = q[0] * m[1] + q[1] * m[4] + q[2] * m[7] + m[10];
+                const double z = q[0] * m[2] + q[1] * m[5] + q[2] * m[8] + m[11];
+                q[0] = x; q[1] = y; q[2] = z;
+            }
+            for (int a = 0; a < 3; ++a) { finite = finite && std::isfinite(q[a]); wlo[a] = std::min(wlo[a], q[a]); whi[a] = std::max(whi[a], q[a]); }
+        }
+        if (!finite) continue;
+        double extent = 0;
+        for (int a = 0; a < 3; ++a) extent = std::max(extent, std::max(std::fabs(wlo[a]), std::fabs(whi[a])));
+        const double padding = 1e-3 * extent + 1e-4;
+        for (int a = 0; a < 3; ++a) { d.wbox[a] = (float)(wlo[a] - padding); d.wbox[3 + a] = (float)(whi[a] + padding); }
+    }
     // ---- textures ----
     const auto tex_ok = [&](int32_t t) { return t >= 0 && (uint32_t)t <= sc->n_textures; };
     if (!tex_ok(sc->background_texture) || !tex_ok(sc->environment_texture)) return ctx->fail(RT_ERR_INVALID, "background / environment texture index out of range");

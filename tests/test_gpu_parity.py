@@ -200,6 +200,24 @@ def test_whitted_spheres_vs_oracle(ctx, bounces, w, h, spp):
     assert abs(int(c.shadow_rays) - int(cpu.stats.shadow)) <= 5e-3 * cpu.stats.shadow
 
 
+@pytest.mark.parametrize("bounces,w,h,spp", [(0, 200, 112, 2), (2, 128, 72, 2)])
+def test_whitted_nested_transforms_vs_oracle(ctx, bounces, w, h, spp):
+    """Rotated, non-uniformly scaled and nested nodes through the Whitted-style shader: the kernel skips objects
+    whose padded world-space box no ray of a wave reaches, the oracle tests every object as the reference does, and
+    depth and ids must not differ in a single pixel."""
+    from raytracer_amd import scenes
+    hs = lib.HostScene.from_string(scenes.nested_scene_xml(w, h).replace('<dof value="0.6"/>', ""))
+    prm = abi.default_params(seed=11, min_spp=spp, max_spp=spp, max_bounces=bounces, mode=abi.RT_MODE_WHITTED)
+    gpu = render_gpu(ctx, hs, prm, w, h)
+    cpu = O.render(hs, prm, w, h)
+    assert np.array_equal(gpu.object_id, cpu.object_id)
+    assert np.array_equal(bits(gpu.z), bits(cpu.z))
+    assert O.psnr(gpu.rgb, cpu.rgb) >= PSNR_MIN
+    c = ctx.counters()
+    assert abs(int(c.closest_rays) - int(cpu.stats.closest)) <= 5e-3 * cpu.stats.closest
+    assert abs(int(c.shadow_rays) - int(cpu.stats.shadow)) <= 5e-3 * cpu.stats.shadow
+
+
 def test_whitted_tile_shards_and_determinism(ctx):
     """Whitted-style frames with photon maps: rendering twice gives the same bits, and three tile shards tile the frame."""
     s = O.scene_from_golden(O.load_golden("scene_a"))
