@@ -223,6 +223,9 @@ def main():
     photon_stats = {}
 
     def step():
+        # the library renders on its own stream: what the previous step queued on torch's stream (unpacking the
+        # gathered pixels, the copy to the host) must be through with the planes before they are written again
+        torch.cuda.current_stream().synchronize()
         if filler:  # the maps are part of the frame: emitted by all ranks, gathered, balanced on every rank
             photon_stats.update(filler(pp))
         ctx.render_device(prm, rgb=fb.rgb.data_ptr(), z=fb.z.data_ptr(), sample_count=fb.sample_count.data_ptr(),
