@@ -79,6 +79,9 @@ struct rt_ctx {
     // photon maps: balanced trees the shader reads, and scratch of the emission launches
     DeviceBuf d_gather_heaps, d_pmap[2], d_ph_raw, d_ph_counts, d_ph_offsets, d_ph_tiles, d_ph_total;
     uint32_t pmap_n[2] = {0, 0};
+    // Node i of a map (1-based, children 2i and 2i+1) sits at byte 32 i of its buffer: one unused slot in front puts
+    // every pair of siblings on one 64-byte line and the four grandchildren of a node on one 128-byte line.
+    rt_photon *pmap(int which) const { return (rt_photon *)((char *)d_pmap[which].p + sizeof(rt_photon)); }
     int pmap_flags = -1; // RT_PM_* bits the maps were filled with, -1 = not known (built from caller's photons)
     std::vector<int32_t> active_host;
     int active_key[5] = {-1, -1, -1, -1, -1};
@@ -716,7 +719,7 @@ int rt_render(rt_ctx *ctx, const rt_render_params *prm, rt_frame_out *out)
             HIP_TRY(ctx, hipEventRecord(ctx->evk0, s));
             if (prm->mode == RT_MODE_WHITTED) {
                 const void *fn = whitted_kernel(ctx->counting, ctx->ray_levels);
-                for (int w = 0; w < 2; ++w) { ctx->scene.pmap[w] = ctx->pmap_n[w] ? ctx->d_pmap[w].as<rt_photon>() : nullptr; ctx->scene.pmap_n[w] = ctx->pmap_n[w]; }
+                for (int w = 0; w < 2; ++w) { ctx->scene.pmap[w] = ctx->pmap_n[w] ? ctx->pmap(w) : nullptr; ctx->scene.pmap_n[w] = ctx->pmap_n[w]; }
                 int per_cu = 1;
                 HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kBlock, lds));
                 per_cu = std::max(1, std::min(per_cu, 8));
@@ -1140,8 +1143,8 @@ int rt_photons_build(rt_ctx *ctx, int which, const rt_photon *photons, uint32_t 
     }
     std::vector<rt_photon> tree;
     rt::build_photon_tree(src, n, tree);
-    HIP_TRY(ctx, ctx->d_pmap[which].reserve((size_t)n * sizeof(rt_photon)));
-    HIP_TRY(ctx, hipMemcpy(ctx->d_pmap[which].p, tree.data(), (size_t)n * sizeof(rt_photon), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, ctx->d_pmap[which].reserve(((size_t)n + 1) * sizeof(rt_photon)));
+    HIP_TRY(ctx, hipMemcpy(ctx->pmap(which), tree.data(), (size_t)n * sizeof(rt_photon), hipMemcpyHostToDevice));
     int levels = 1;
     while ((1u << levels) <= n) ++levels; // tree height
     if (int rc = ensure_stack_levels(ctx, levels + 1)) return rc;
@@ -1197,7 +1200,7 @@ int rt_photons_download(rt_ctx *ctx, int which, rt_photon *dst, uint32_t *n)
     *n = ctx->pmap_n[which];
     if (!dst || *n == 0) return RT_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipMemcpy(dst, ctx->d_pmap[which].p, (size_t)*n * sizeof(rt_photon), hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(dst, ctx->pmap(which), (size_t)*n * sizeof(rt_photon), hipMemcpyDeviceToHost));
     return RT_OK;
 }
 
@@ -1219,7 +1222,7 @@ int rt_photons_irradiance(rt_ctx *ctx, int which, const float *pos3, const float
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters.p, 0, sizeof(DCounters), s));
     HIP_TRY(ctx, hipEventRecord(ctx->evk0, s));
     hipLaunchKernelGGL(k_photon_irradiance, batch_grid(ctx, n), dim3(kBlock), gather_lds_bytes(ctx->scene), s, ctx->scene,
-                       ctx->d_pmap[which].as<rt_photon>(), ctx->pmap_n[which], ctx->d_q_in.as<float>(), ctx->d_q_aux.as<float>(), n, radius,
+                       ctx->pmap(which), ctx->pmap_n[which], ctx->d_q_in.as<float>(), ctx->d_q_aux.as<float>(), n, radius,
                        ctx->d_q_out.as<float>(), ctx->d_counters.as<DCounters>());
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->evk1, s));
