@@ -58,7 +58,7 @@ struct rt_ctx {
     bool have_camera = false;
     rt_camera camera{};
     // frame
-    DeviceBuf d_halton, d_active[2], d_next_count, d_state, d_sbuf, d_counters, d_queue;
+    DeviceBuf d_halton, d_active[2], d_active_all, d_next_count, d_state, d_sbuf, d_counters, d_queue;
     DeviceBuf d_stack_ovf;
     // wavefront pipeline: path pool, ray queue, counters {count, alive, pad, pad, head(u64), item(u64)}
     DeviceBuf d_pool, d_wq_ctr;
@@ -675,11 +675,15 @@ int rt_render(rt_ctx *ctx, const rt_render_params *prm, rt_frame_out *out)
             const int tw = std::min(ts, W - x0), th = std::min(ts, H - y0);
             for (int j = y0; j < y0 + th; ++j) for (int i = x0; i < x0 + tw; ++i) ctx->active_host.push_back(j * W + i);
         }
+        // the shard's whole list stays on the device (8 MB at 1080p: a millisecond of upload per frame otherwise); the
+        // first sampling round reads it, the later rounds' shrinking lists alternate between the two d_active buffers
+        HIP_TRY(ctx, ctx->d_active_all.reserve(sizeof(int32_t) * std::max<size_t>(1, ctx->active_host.size())));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_active_all.p, ctx->active_host.data(), sizeof(int32_t) * ctx->active_host.size(), hipMemcpyHostToDevice, s));
+        HIP_TRY(ctx, hipStreamSynchronize(s));
         memcpy(ctx->active_key, key, sizeof key);
     }
     const uint32_t n0 = (uint32_t)ctx->active_host.size();
     for (auto &b : ctx->d_active) HIP_TRY(ctx, b.reserve(sizeof(int32_t) * std::max<uint32_t>(1, n0)));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_active[0].p, ctx->active_host.data(), sizeof(int32_t) * n0, hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, ctx->d_state.reserve(sizeof(PixelState) * npx));
 
     // output planes: the caller's device memory, or internal planes copied out afterwards
@@ -715,7 +719,7 @@ int rt_render(rt_ctx *ctx, const rt_render_params *prm, rt_frame_out *out)
         for (uint32_t first = 0; first < n_active; first += chunk_px) {
             const uint32_t cnt = std::min(chunk_px, n_active - first);
             const uint64_t items = (uint64_t)cnt * nk;
-            const int32_t *act = ctx->d_active[cur].as<int32_t>() + first;
+            const int32_t *act = (k0 == 0 ? ctx->d_active_all.as<int32_t>() : ctx->d_active[cur].as<int32_t>()) + first;
             HIP_TRY(ctx, hipEventRecord(ctx->evk0, s));
             if (prm->mode == RT_MODE_WHITTED) {
                 const void *fn = whitted_kernel(ctx->counting, ctx->ray_levels);
