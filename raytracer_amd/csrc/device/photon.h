@@ -346,11 +346,35 @@ RT_DEV LaneHeap lane_heap(const DScene &S, uint32_t *lds)
     return h;
 }
 
+// The walk's stack (one entry per tree level) on top of a lane's BVH stack storage, turned upside down: a BVH walk
+// is busiest near the bottom of its stack, a kd-tree walk near the top (the levels next to the leaves), so here the
+// *deepest* lds_levels levels are the ones in LDS and the levels next to the root go to the overflow array.
+struct KdStack {
+    LaneStack st;
+    uint32_t base; // first level kept in LDS = levels that live in the overflow array
+    RT_DEV KdStack(const LaneStack &s, uint32_t ovf_levels) : st(s), base(ovf_levels) {}
+    RT_DEV void push(int sp, uint32_t data, float dist) const
+    {
+        const u32x2 e = {data, __float_as_uint(dist)};
+        if ((uint32_t)sp >= base) st.lds[((uint32_t)sp - base) * kStackStride] = e;
+        else st.ovf[(size_t)(uint32_t)sp * st.ovf_stride] = e;
+    }
+    RT_DEV void pop(int sp, uint32_t &data, float &dist) const
+    {
+        u32x2 e;
+        if ((uint32_t)sp >= base) e = st.lds[((uint32_t)sp - base) * kStackStride];
+        else e = st.ovf[(size_t)(uint32_t)sp * st.ovf_stride];
+        data = e.x; dist = __uint_as_float(e.y);
+    }
+};
+
 template <bool COUNT>
-RT_DEV V3 photon_irradiance(const rt_photon *tree0, uint32_t n, V3 pos, V3 normal, float radius, LaneStack st,
+RT_DEV V3 photon_irradiance(const rt_photon *tree0, uint32_t n, V3 pos, V3 normal, float radius, LaneStack lane_st,
                             const LaneHeap H, uint32_t &visits)
 {
     if (n == 0) return mk(0, 0, 0);
+    const uint32_t height = 32u - (uint32_t)__clz((int)n); // levels of the balanced tree = most stack entries + 1
+    const KdStack st(lane_st, height > lane_st.lds_levels ? height - lane_st.lds_levels : 0u);
     const GF4 tree = (GF4)(const void *)tree0 - 2; // node i = tree[2 i], tree[2 i + 1]
     const int half = (int)n / 2 - 1;               // nodes below this index are treated as internal (src/photonmap.h:197,346)
     int found = 0;
