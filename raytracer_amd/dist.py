@@ -52,6 +52,11 @@ class FrameGather:
         self.idx = [torch.from_numpy(x.astype(np.int64)).to(device) for x in lists]
         self.send = torch.zeros((self.n_max, PACK), dtype=torch.uint8, device=device)
         self.recv = torch.zeros((world, self.n_max, PACK), dtype=torch.uint8, device=device)
+        # the other ranks' pixels in one go: rows of the flattened receive buffer and the pixels they belong to
+        rows = [r * self.n_max + np.arange(len(lists[r]), dtype=np.int64) for r in range(world) if r != rank]
+        dest = [lists[r].astype(np.int64) for r in range(world) if r != rank]
+        self.rows = torch.from_numpy(np.concatenate(rows) if rows else np.zeros(0, np.int64)).to(device)
+        self.dest = torch.from_numpy(np.concatenate(dest) if dest else np.zeros(0, np.int64)).to(device)
 
     def __call__(self, fb):
         if self.world == 1:
@@ -64,16 +69,12 @@ class FrameGather:
         s[:n, 7:11] = fb.sample_count[mine].view(torch.uint8).reshape(n, 4)
         s[:n, 11:15] = fb.object_id[mine].view(torch.uint8).reshape(n, 4)
         dist.all_gather_into_tensor(self.recv.view(-1), s.view(-1))
-        for r in range(self.world):
-            if r == self.rank:
-                continue
-            idx = self.idx[r]
-            m = len(idx)
-            blk = self.recv[r, :m]
-            fb.rgb[idx] = blk[:, 0:3]
-            fb.z[idx] = blk[:, 3:7].contiguous().view(torch.float32).reshape(m)
-            fb.sample_count[idx] = blk[:, 7:11].contiguous().view(torch.int32).reshape(m)
-            fb.object_id[idx] = blk[:, 11:15].contiguous().view(torch.int32).reshape(m)
+        blk = self.recv.view(-1, PACK)[self.rows]
+        m = len(self.dest)
+        fb.rgb[self.dest] = blk[:, 0:3]
+        fb.z[self.dest] = blk[:, 3:7].contiguous().view(torch.float32).reshape(m)
+        fb.sample_count[self.dest] = blk[:, 7:11].contiguous().view(torch.int32).reshape(m)
+        fb.object_id[self.dest] = blk[:, 11:15].contiguous().view(torch.int32).reshape(m)
         return fb
 
 
