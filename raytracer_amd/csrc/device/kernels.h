@@ -270,6 +270,38 @@ __global__ __launch_bounds__(kBlock) void k_probe(DScene S, DFrame F, const floa
     if ((threadIdx.x & 63) == 0) atomicAdd(&ctr->paths, (unsigned long long)p);
 }
 
+// Scheduling keys: what the first sample's camera ray costs (box and triangle tests; 0 for a ray that misses
+// everything).  Pixels whose camera ray is expensive tend to have expensive paths (long walks over grazing
+// geometry, glossy or glass surfaces), and a launch ends sooner if they start first: the host sorts the pixel
+// list by this key, descending, before the first sampling round.  The order decides only when a pixel is
+// rendered, never what it looks like.
+template <int LEVELS>
+__global__ __launch_bounds__(kBlock) void k_order_keys(DScene S, DFrame F, const float *__restrict__ halton,
+                                                       const int32_t *__restrict__ active, uint32_t n, uint32_t *__restrict__ keys)
+{
+    extern __shared__ uint32_t lds[];
+    const LaneStack st = lane_stack(lds, S);
+    for (uint32_t a = blockIdx.x * kBlock + threadIdx.x; a < n; a += gridDim.x * kBlock) {
+        const int pix = active[a];
+        const uint64_t seed = pixel_seed(F.seed, (uint64_t)pix);
+        Rng rng;
+        rng_set_sequence(rng, 0, seed);
+        float off[4];
+        off[0] = rng_float(rng); off[1] = rng_float(rng); off[2] = rng_float(rng); off[3] = rng_float(rng);
+        const Ray ray = camera_ray(F, halton, pix % F.width, pix / F.width, 0, off);
+        Hit h;
+        Tally<true> tl;
+        const bool hit = trace_closest<true, LEVELS>(S, ray, st, h, tl);
+        const rt_material &m = S.materials[hit && h.node >= 0 ? S.nodes[h.node].material : 0];
+        // a surface that keeps a path going (glossy, glass) weighs more than one that mostly ends it
+        const float keep = hit && h.node >= 0 ? gray(m.specular) + gray(m.refraction) : 0.0f;
+        const uint32_t walk = tl.box + 4u * tl.tri;
+        // 24 bits: how much of a path the surface keeps going first, the cost of the walk second
+        const uint32_t k_keep = (uint32_t)((keep < 1.0f ? keep : 1.0f) * 255.0f);
+        keys[a] = hit ? (k_keep << 16) | (walk < 65535u ? walk + 1u : 65535u) : 0u;
+    }
+}
+
 // int(float) as x86 cvttss2si does it: NaN and out-of-range give INT_MIN
 RT_DEV int x86_f2i(float f)
 {

@@ -1,6 +1,7 @@
 // C ABI of the GPU backend: context, scene upload, frame rendering, batch queries.
 // Host-side control only; the arithmetic lives in device/*.h.
 #include "device/pathsm.h"
+#include <hipcub/hipcub.hpp>
 #include "device/whitted.h"
 #include "host/photon_map.h"
 #include "rt_mi355x.h"
@@ -58,7 +59,8 @@ struct rt_ctx {
     bool have_camera = false;
     rt_camera camera{};
     // frame
-    DeviceBuf d_halton, d_active[2], d_active_all, d_next_count, d_state, d_sbuf, d_counters, d_queue;
+    DeviceBuf d_halton, d_active[2], d_active_all, d_active_sorted, d_keys[2], d_sort_tmp, d_next_count, d_state, d_sbuf, d_counters, d_queue;
+    int order_pixels = -1;    // RT_ORDER: 1 = always deal a frame's pixels expensive-first, 0 = never (tile order), default: for tile shards only
     DeviceBuf d_stack_ovf;
     // wavefront pipeline: path pool, ray queue, counters {count, alive, pad, pad, head(u64), item(u64)}
     DeviceBuf d_pool, d_wq_ctr;
@@ -374,6 +376,7 @@ int rt_init(int device, rt_ctx **out)
                           (const void *)k_whitted<false, 1>, (const void *)k_whitted<false, 2>, (const void *)k_whitted<false, 5>,
                           (const void *)k_whitted<true, 1>, (const void *)k_whitted<true, 2>, (const void *)k_whitted<true, 5>,
                           (const void *)k_probe<1>, (const void *)k_probe<2>, (const void *)k_probe<5>,
+                          (const void *)k_order_keys<1>, (const void *)k_order_keys<2>, (const void *)k_order_keys<5>,
                           (const void *)k_trace, (const void *)k_trace_shadow, (const void *)k_trace_paths})
         (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     for (const void *k : {(const void *)k_photon_paths<false, 1>, (const void *)k_photon_paths<false, 2>, (const void *)k_photon_paths<false, 5>,
@@ -394,6 +397,7 @@ int rt_init(int device, rt_ctx **out)
         if ((e = hipEventCreateWithFlags(&ctx->pool_event[i], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     }
     if ((e = hipEventCreateWithFlags(&ctx->fork_event, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+    if (const char *e7 = getenv("RT_ORDER")) ctx->order_pixels = atoi(e7) != 0 ? 1 : 0;
     if (const char *e2 = getenv("RT_LDS_LEVELS")) ctx->lds_levels_max = std::max(1, std::min(64, atoi(e2))); // tuning knob
     if ((e = ctx->d_queue.reserve(kQueueBytes)) != hipSuccess) return bail("hipMalloc", e);
     *out = ctx;
@@ -706,6 +710,33 @@ int rt_render(rt_ctx *ctx, const rt_render_params *prm, rt_frame_out *out)
     uint32_t launches = 0;
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, s));
 
+    // Expensive pixels first (path frames): keys from one camera ray per pixel, then a stable descending radix sort.
+    // A launch ends with a tail of a few milliseconds in which the last long paths run alone; it is shorter when the
+    // long paths started first.  On the whole 1080p frame the tail is 3 % and the keys cost as much as they save
+    // (0.6 ms); on the 1/8 shard of an 8-GPU run the launch is 1.0 ms shorter (22.4 -> 21.4 ms), so it is on for shards.
+    const int32_t *first_list = ctx->d_active_all.as<int32_t>();
+    const bool order = ctx->order_pixels < 0 ? prm->tile_world > 1 : ctx->order_pixels != 0;
+    if (order && prm->mode == RT_MODE_PATH && prm->max_bounces > 0 && n0 > 1) {
+        HIP_TRY(ctx, ctx->d_active_sorted.reserve(sizeof(int32_t) * n0));
+        for (auto &b : ctx->d_keys) HIP_TRY(ctx, b.reserve(sizeof(uint32_t) * n0));
+        const void *fn = ctx->ray_levels <= 1 ? (const void *)k_order_keys<1> : ctx->ray_levels == 2 ? (const void *)k_order_keys<2> : (const void *)k_order_keys<5>;
+        const dim3 grid((unsigned)std::min<uint64_t>(((uint64_t)n0 + kBlock - 1) / kBlock, ctx->ovf_threads / kBlock));
+        DScene a_scene = ctx->scene;
+        const float *a_hal = ctx->d_halton.as<float>();
+        const int32_t *a_act = first_list;
+        uint32_t a_n = n0;
+        uint32_t *a_keys = ctx->d_keys[0].as<uint32_t>();
+        void *args[] = {&a_scene, &F, &a_hal, &a_act, &a_n, &a_keys};
+        HIP_TRY(ctx, hipLaunchKernel(fn, grid, dim3(kBlock), args, stack_lds_bytes(ctx->scene), s));
+        size_t tmp_bytes = 0;
+        HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tmp_bytes, ctx->d_keys[0].as<uint32_t>(), ctx->d_keys[1].as<uint32_t>(),
+                                                                  first_list, ctx->d_active_sorted.as<int32_t>(), (int)n0, 0, 24, s));
+        HIP_TRY(ctx, ctx->d_sort_tmp.reserve(std::max<size_t>(1, tmp_bytes)));
+        HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairsDescending(ctx->d_sort_tmp.p, tmp_bytes, ctx->d_keys[0].as<uint32_t>(), ctx->d_keys[1].as<uint32_t>(),
+                                                                  first_list, ctx->d_active_sorted.as<int32_t>(), (int)n0, 0, 24, s));
+        first_list = ctx->d_active_sorted.as<int32_t>();
+    }
+
     // sampling rounds: the first takes min_spp samples of every pixel, later ones
     // up to 16 more of the pixels the stop test has not released yet
     const uint64_t kMaxItems = 1ull << 28; // bounds the sample buffer to 4 GiB
@@ -719,7 +750,7 @@ int rt_render(rt_ctx *ctx, const rt_render_params *prm, rt_frame_out *out)
         for (uint32_t first = 0; first < n_active; first += chunk_px) {
             const uint32_t cnt = std::min(chunk_px, n_active - first);
             const uint64_t items = (uint64_t)cnt * nk;
-            const int32_t *act = (k0 == 0 ? ctx->d_active_all.as<int32_t>() : ctx->d_active[cur].as<int32_t>()) + first;
+            const int32_t *act = (k0 == 0 ? first_list : ctx->d_active[cur].as<int32_t>()) + first;
             HIP_TRY(ctx, hipEventRecord(ctx->evk0, s));
             if (prm->mode == RT_MODE_WHITTED) {
                 const void *fn = whitted_kernel(ctx->counting, ctx->ray_levels);
