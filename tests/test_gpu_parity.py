@@ -360,6 +360,39 @@ def test_pipelines_agree(monkeypatch):
             c.close()
 
 
+def test_pixel_order_does_not_change_the_frame(monkeypatch):
+    """Dealing a frame's pixels expensive-first (scheduling keys from one camera ray per pixel + radix sort; the
+    default for tile shards) only changes when a pixel is rendered: every plane, the adaptive sample counts and
+    the ray counts are those of tile order, for whole frames and for shards."""
+    ctxs = {}
+    for order in ("0", "1"):
+        monkeypatch.setenv("RT_ORDER", order)
+        ctxs[order] = lib.Context(0)
+    monkeypatch.delenv("RT_ORDER")
+    try:
+        for name, (w, h, mn, mx) in {"scene_a": (200, 120, 4, 12), "scene_mesh": (160, 90, 3, 20)}.items():
+            s = O.scene_from_golden(O.load_golden(name))
+            for world in (1, 3):
+                frames, counts = {}, {}
+                for order, c in ctxs.items():
+                    c.upload(s.desc)
+                    c.set_camera(s.camera, w, h)
+                    merged = lib.Frame(w, h)
+                    total = [0, 0, 0]
+                    for rank in range(world):
+                        c.render(abi.default_params(seed=23, min_spp=mn, max_spp=mx, delta_max=0.02, tile_rank=rank, tile_world=world), merged)
+                        k = c.counters()
+                        total = [total[0] + k.closest_rays, total[1] + k.shadow_rays, total[2] + k.camera_paths]
+                    frames[order], counts[order] = merged, total
+                for plane in ("rgb", "z", "sample_count", "object_id"):
+                    assert np.array_equal(getattr(frames["0"], plane), getattr(frames["1"], plane)), (name, world, plane)
+                assert np.array_equal(bits(frames["0"].linear), bits(frames["1"].linear)), (name, world)
+                assert counts["0"] == counts["1"], (name, world)
+    finally:
+        for c in ctxs.values():
+            c.close()
+
+
 def test_edge_cases(ctx):
     s = O.scene_from_golden(O.load_golden("scene_a"))
     # image smaller than a tile, odd sizes, one sample, no bounces
