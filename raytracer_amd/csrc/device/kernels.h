@@ -120,7 +120,10 @@ RT_DEV Ray camera_ray(const DFrame &F, const float *halton, int i, int j, int k,
 #ifndef RT_QUEUES
 #define RT_QUEUES 1
 #endif
-constexpr uint32_t kChunk = 512;
+#ifndef RT_CHUNK
+#define RT_CHUNK 512
+#endif
+constexpr uint32_t kChunk = RT_CHUNK;
 constexpr uint32_t kQueues = RT_QUEUES;
 constexpr uint32_t kQueueStride = 16; // unsigned long longs between queue words (128 bytes)
 constexpr size_t kQueueBytes = kQueues * kQueueStride * sizeof(unsigned long long);
@@ -131,10 +134,12 @@ struct WorkQueue {
     uint32_t q, tried;      // current part, parts found empty so far
     uint64_t next = 0, end = 0;
     bool exhausted = false;
-    RT_DEV WorkQueue(unsigned long long *w, uint64_t n) : words(w), n_items(n)
+    uint32_t chunk; // items per draw: large chunks keep a wave on neighbouring pixels (coherent walks), small ones even
+                    // out the end of the launch; the host picks it from the items each wave will get (DFrame::chunk)
+    RT_DEV WorkQueue(unsigned long long *w, uint64_t n, uint32_t chunk_items = kChunk) : words(w), n_items(n), chunk(chunk_items)
     {
-        const uint64_t chunks = (n + kChunk - 1) / kChunk;
-        part = ((chunks + kQueues - 1) / kQueues) * kChunk;
+        const uint64_t chunks = (n + chunk - 1) / chunk;
+        part = ((chunks + kQueues - 1) / kQueues) * chunk;
         q = blockIdx.x % kQueues;
         tried = 0;
     }
@@ -143,11 +148,11 @@ struct WorkQueue {
     {
         while (next >= end && !exhausted) {
             unsigned long long b = 0;
-            if (lane == 0) b = atomicAdd(&words[q * kQueueStride], (unsigned long long)kChunk);
+            if (lane == 0) b = atomicAdd(&words[q * kQueueStride], (unsigned long long)chunk);
             b = __shfl(b, 0, 64);
             const uint64_t lo = (uint64_t)q * part, hi = lo + part < n_items ? lo + part : n_items;
             const uint64_t s = lo + b;
-            if (s < hi) { next = s; end = s + kChunk < hi ? s + kChunk : hi; }
+            if (s < hi) { next = s; end = s + chunk < hi ? s + chunk : hi; }
             else if (++tried >= kQueues) exhausted = true;
             else q = (q + 1) % kQueues;
         }
@@ -174,7 +179,10 @@ __global__ __launch_bounds__(kBlock, RT_PATHS_MIN_WAVES) void k_paths(DScene S, 
     Tally<COUNT> tl;
     uint32_t paths = 0;
 
-    WorkQueue wq(queue, n_items); // wave-uniform
+#ifdef RT_PROFILE_TAIL
+    const unsigned long long tail_t0 = wall_clock64();
+#endif
+    WorkQueue wq(queue, n_items, F.chunk); // wave-uniform
     bool alive = false;
     uint64_t item = 0;
     int pix = 0, k = 0;
@@ -234,6 +242,17 @@ __global__ __launch_bounds__(kBlock, RT_PATHS_MIN_WAVES) void k_paths(DScene S, 
         }
     }
     flush_counters<COUNT>(ctr, pt, tl, paths);
+#ifdef RT_PROFILE_TAIL
+    // diagnostic build: when does each wave run out of work?  phase[12] = earliest wave start, [13] = latest wave end,
+    // [14] = sum of wave ends, [15] = waves (100 MHz clock); the mean of (latest end - wave end) is the launch's tail
+    if (lane == 0) {
+        const unsigned long long t1 = wall_clock64();
+        atomicMin(&ctr->phase[12], tail_t0);
+        atomicMax(&ctr->phase[13], t1);
+        atomicAdd(&ctr->phase[14], t1 - tail_t0);
+        atomicAdd(&ctr->phase[15], 1ull);
+    }
+#endif
 }
 
 // Zero bounces: tracePath's loop body never runs, so every sample is black; only the depth / id planes need the

@@ -84,6 +84,8 @@ struct DFrame {
     uint64_t seed;
     int32_t photon_flags; // RT_PM_* bits the Whitted-style shader honours
     float gather_radius;
+    uint32_t chunk;       // items a wave of the path kernel draws from the work queue at a time
+    uint32_t pad_;
 };
 
 struct DCounters {

@@ -523,8 +523,8 @@ RT_DEV bool reaches_box(const float *b, V3 p, V3 inv, float t_max)
     const float x1 = (b[0] - p.x) * inv.x, x2 = (b[3] - p.x) * inv.x;
     const float y1 = (b[1] - p.y) * inv.y, y2 = (b[4] - p.y) * inv.y;
     const float z1 = (b[2] - p.z) * inv.z, z2 = (b[5] - p.z) * inv.z;
-    const float tNear = vmax(vmax3(vmin(x1, x2), vmin(y1, y2), vmin(z1, z2)), 0.0f);
-    const float tFar = vmin(vmin3(vmax(x1, x2), vmax(y1, y2), vmax(z1, z2)), t_max);
+    const float tNear = fmaxf(fmaxf(fmaxf(fminf(x1, x2), fminf(y1, y2)), fminf(z1, z2)), 0.0f);
+    const float tFar = fminf(fminf(fminf(fmaxf(x1, x2), fmaxf(y1, y2)), fmaxf(z1, z2)), t_max);
     return !(tNear > tFar);
 }
 
@@ -533,6 +533,13 @@ RT_DEV bool reaches_box(const float *b, V3 p, V3 inv, float t_max)
 // the reference's per-level comparisons select.
 // With CULL an object none of the wave's rays can reach (its world-space box is missed, or lies behind the closest
 // hit so far: t is the same in every node's space) is skipped by the whole wave.
+// NOT USED BY DEFAULT.  The vote made the 64-sphere Whitted frame 1.5 x faster and its frames were bit-exact in every
+// test for a while, but the result depends on how the compiler lays out the kernel around the vote: with two votes per
+// node (one on either side of the matrix load) 162 pixels of a 200x112 frame lost their nearest object, and after an
+// unrelated change elsewhere in the library the depth plane of a 96x54 frame took 316 values of other samples of the
+// same pixels while the vote in trace_shadow() was compiled in (not with the one in trace_closest() alone).  The
+// per-lane arithmetic cannot do either; until the control flow around the vote is understood the kernels are built
+// without it (RT_WHITTED_CULL=1 builds it in).
 template <bool COUNT, int LEVELS, bool CULL = false>
 RT_DEV bool trace_closest(const DScene &S, Ray ray, LaneStack st, Hit &h, Tally<COUNT> &tl)
 {

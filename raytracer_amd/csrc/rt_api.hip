@@ -60,6 +60,7 @@ struct rt_ctx {
     rt_camera camera{};
     // frame
     DeviceBuf d_halton, d_active[2], d_active_all, d_active_sorted, d_keys[2], d_sort_tmp, d_next_count, d_state, d_sbuf, d_counters, d_queue;
+    int chunk_items = 0;      // RT_CHUNK_ITEMS: fixed work-queue chunk of the path kernel (experiments), 0 = chosen per launch
     int order_pixels = -1;    // RT_ORDER: 1 = always deal a frame's pixels expensive-first, 0 = never (tile order), default: for tile shards only
     DeviceBuf d_stack_ovf;
     // wavefront pipeline: path pool, ray queue, counters {count, alive, pad, pad, head(u64), item(u64)}
@@ -179,6 +180,7 @@ void fill_frame(const rt_ctx *ctx, const rt_render_params *p, DFrame &F)
     F.max_bounces = p->max_bounces; F.bias = p->bias; F.halton_period = p->halton_period; F.seed = p->seed;
     F.photon_flags = p->mode == RT_MODE_WHITTED ? p->photon_flags : 0;
     F.gather_radius = p->gather_radius;
+    F.chunk = kChunk;
 }
 
 template <bool TEXBG> const void *paths_kernel_lockstep(bool counting, int ray_levels)
@@ -397,6 +399,7 @@ int rt_init(int device, rt_ctx **out)
         if ((e = hipEventCreateWithFlags(&ctx->pool_event[i], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     }
     if ((e = hipEventCreateWithFlags(&ctx->fork_event, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+    if (const char *e8 = getenv("RT_CHUNK_ITEMS")) ctx->chunk_items = std::max(0, atoi(e8)) / 64 * 64;
     if (const char *e7 = getenv("RT_ORDER")) ctx->order_pixels = atoi(e7) != 0 ? 1 : 0;
     if (const char *e2 = getenv("RT_LDS_LEVELS")) ctx->lds_levels_max = std::max(1, std::min(64, atoi(e2))); // tuning knob
     if ((e = ctx->d_queue.reserve(kQueueBytes)) != hipSuccess) return bail("hipMalloc", e);
@@ -704,6 +707,9 @@ int rt_render(rt_ctx *ctx, const rt_render_params *prm, rt_frame_out *out)
     }
 
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters.p, 0, sizeof(DCounters), s));
+#ifdef RT_PROFILE_TAIL
+    HIP_TRY(ctx, hipMemsetAsync((char *)ctx->d_counters.p + offsetof(DCounters, phase) + 12 * 8, 0xFF, 8, s)); // the minimum starts at the top
+#endif
     const bool gathers = prm->mode == RT_MODE_WHITTED && prm->photon_flags != 0;
     const size_t lds = gathers ? gather_lds_bytes(ctx->scene) : stack_lds_bytes(ctx->scene);
     double trace_ms = 0.0;
@@ -784,6 +790,16 @@ int rt_render(rt_ctx *ctx, const rt_render_params *prm, rt_frame_out *out)
                 if (int rc = render_wavefront(ctx, F, act, items, k0, nk, P, lds)) return rc;
             } else {
             // persistent launch: as many workgroups as the chip holds at once (more would only queue up)
+            {
+                // Items per draw from the work queue.  Large chunks keep a wave on neighbouring pixels (a wave is 1 %
+                // busier per halving: 144.5 / 146.1 / 150.1 / 157.4 ms of work per wave for 512 / 256 / 128 / 64 on the
+                // 1080p frame), small ones even out the end of the launch (a wave of a 1/8 shard draws five chunks of 512
+                // in all, and waits 3.1 ms on average for the slowest wave; 1.1 ms with 256): about a sixteenth of what
+                // a wave will get, as a power of two between 256 and 1024.
+                const uint64_t per_wave = items / ((uint64_t)ctx->n_cu * 6 * (kBlock / 64)) / 16;
+                F.chunk = per_wave >= 1024 ? 1024u : per_wave >= 512 ? 512u : 256u;
+                if (ctx->chunk_items > 0) F.chunk = (uint32_t)ctx->chunk_items;
+            }
             const void *fn = paths_kernel(ctx->counting, ctx->ray_levels, ctx->use_lockstep, ctx->scene.background_texture > 0);
             int per_cu = 1;
             HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kBlock, lds));
