@@ -766,6 +766,11 @@ int rt_render(rt_ctx *ctx, const rt_render_params *prm, rt_frame_out *out)
                 per_cu = std::max(1, std::min(per_cu, 8));
                 const dim3 grid((unsigned)std::min<uint64_t>((items + kBlock - 1) / kBlock, (uint64_t)ctx->n_cu * per_cu));
                 HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue.p, 0, kQueueBytes, s));
+                {   // items per draw from the work queue: about a sixteenth of what a wave will get (see the path kernel below)
+                    const uint64_t per_wave = items / ((uint64_t)grid.x * (kBlock / 64)) / 16;
+                    F.chunk = per_wave >= 512 ? 512u : per_wave >= 256 ? 256u : per_wave >= 128 ? 128u : 64u;
+                    if (ctx->chunk_items > 0) F.chunk = (uint32_t)ctx->chunk_items;
+                }
                 DScene a_scene = ctx->scene;
                 const float *a_hal = ctx->d_halton.as<float>();
                 uint64_t a_items = items;
