@@ -10,6 +10,8 @@ reference source text.
     python oracle/make_golden.py            # regenerate everything
     python oracle/make_golden.py --whitted  # only the project-12 (Whitted-style shader) fixtures
     python oracle/make_golden.py --photons  # only the photon-map fixtures
+    python oracle/make_golden.py --config-c       # only the full-size 1M-triangle band and ray fixture
+    python oracle/make_golden.py --photons-large  # only the tall photon map
 """
 import os
 import subprocess
@@ -126,8 +128,52 @@ def textures():
         save("whitted_textured_96x54_b5", **common, **st12, params=np.array([7, 4, 4, 96, 54, 5], np.int64), delta=np.float32(0.01), **out)
 
 
+def config_c():
+    """The 1M-triangle configuration at its full size (1000 x 500 quads, BVH depth 24, 1920x1080): a 16-row band of
+    the frame through every object of the scene, and rays aimed at the mesh.  The mesh arrays are far too large
+    for a fixture: the fixture holds SHA-256 digests of the reference's arrays (vertices, computed normals, faces,
+    BVH nodes and elements), which the library's own OBJ reader / normal computation / BVH builder must reproduce
+    from the generated mesh."""
+    import hashlib
+    with tempfile.TemporaryDirectory() as tmp:
+        mesh = scenes.heightfield(1000, 500)
+        scenes.write_obj(os.path.join(tmp, "mesh_1m.obj"), mesh)
+        xml = scenes.mesh_scene_xml("mesh_1m.obj", 1920, 1080)
+        p = os.path.join(tmp, "scene.xml")
+        open(p, "w").write(xml)
+        sc = scene_bundle(p, cwd=tmp)
+        digests = {}
+        small = {}
+        for k, v in sc.items():
+            if k.startswith("scene_mesh0_"):
+                if k.endswith("bvh_nodes"):
+                    v = v[1:]  # cyBVH leaves node 0 unused (and unwritten)
+                digests[k.replace("scene_", "sha256_")] = np.frombuffer(hashlib.sha256(np.ascontiguousarray(v).tobytes()).digest(), np.uint8)
+                small["count_" + k[len("scene_"):]] = np.int64(len(v))
+            else:
+                small[k] = v
+        common = dict(xml=np.frombuffer(xml.encode(), np.uint8), mesh_nx=np.int32(1000), mesh_ny=np.int32(500), **small, **digests)
+        y0, y1 = 416, 432
+        band = run(p, "render", 7, 4, 4, 0.01, 1920, 1080, y0, y1, cwd=tmp)
+        kat = run(p, "kat_trace", 8192, 31, 40, 1, cwd=tmp)
+        save("config_c_1m", **common, params=np.array([7, 4, 4, 1920, 1080, y0, y1], np.int64), delta=np.float32(0.01), **band, **kat)
+
+
+def photons_large():
+    """A photon map tall enough (>= 32768 photons: 16 levels) that the kd-tree walk of a lookup leaves the levels the
+    GPU keeps in fast memory; otherwise as photons()."""
+    HPM = os.path.join(HERE, "_ref", "ref_harness_p12pm")
+    sa = scene_bundle(REF_SCENE, harness=HPM)
+    r = run(REF_SCENE, "photons", 13, 36000, 17000, 64, 512, 3, harness=HPM)
+    save("photons_a_large", **sa, params=np.array([13, 36000, 17000, 64, 2 | 4], np.int64), radius=np.float32(3), **r)
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
+    if "--config-c" in sys.argv:
+        return config_c()
+    if "--photons-large" in sys.argv:
+        return photons_large()
     if "--textures" in sys.argv:
         return textures()
     if "--whitted" in sys.argv:  # only the snapshot's fixtures
@@ -185,6 +231,8 @@ def main():
     whitted()
     photons()
     textures()
+    config_c()
+    photons_large()
 
 
 if __name__ == "__main__":

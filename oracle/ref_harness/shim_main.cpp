@@ -739,7 +739,9 @@ static void cmdKatRng()
 }
 
 // random rays against the loaded scene through the reference's own TraceRay / TraceShadowRay
-static void cmdKatTrace(int n, uint64_t seed, float extent)
+// aimed != 0: rays for a height-field mesh lying in |x| <= extent/2, |y| <= extent/4 around z = 0: half of them come
+// down onto the mesh from above, half travel nearly horizontally through its relief (long BVH walks, many leaves)
+static void cmdKatTrace(int n, uint64_t seed, float extent, int aimed = 0)
 {
     flattenScene();
     RNG g(77, seed);
@@ -748,6 +750,23 @@ static void cmdKatTrace(int n, uint64_t seed, float extent)
     const Camera &cam = renderer.GetCamera();
     for (int i = 0; i < n; ++i) {
         Ray r;
+        if (aimed) {
+            const float hx = extent * 0.5f, hy = extent * 0.25f;
+            Vec3f tgt;
+            if (i & 1) {
+                r.p = Vec3f{ (g.RandomFloat() - 0.5f) * 2.2f * hx, (g.RandomFloat() - 0.5f) * 2.2f * hy, (g.RandomFloat() - 0.5f) * 5.0f };
+                tgt = Vec3f{ (g.RandomFloat() - 0.5f) * 2.0f * hx, (g.RandomFloat() - 0.5f) * 2.0f * hy, (g.RandomFloat() - 0.5f) * 5.0f };
+            } else {
+                r.p = Vec3f{ (g.RandomFloat() - 0.5f) * 2.5f * hx, (g.RandomFloat() - 0.5f) * 2.5f * hy, 3.0f + g.RandomFloat() * 20.0f };
+                tgt = Vec3f{ (g.RandomFloat() - 0.5f) * 2.0f * hx, (g.RandomFloat() - 0.5f) * 2.0f * hy, (g.RandomFloat() - 0.5f) * 3.0f };
+            }
+            r.dir = tgt - r.p;
+            if ((i % 4) == 3) r.dir.Normalize();
+            float tm = g.RandomFloat() * 2.0f;
+            if ((i % 4) == 3) tm *= 20.0f;
+            memcpy(&rays[(size_t)i * 6], &r.p.x, 12); memcpy(&rays[(size_t)i * 6 + 3], &r.dir.x, 12);
+            tmax[i] = tm;
+        } else {
         // mix of rays starting near the camera and rays starting inside the scene volume
         if (i & 1) r.p = cam.pos + Vec3f{ g.RandomFloat() - 0.5f, g.RandomFloat() - 0.5f, g.RandomFloat() - 0.5f };
         else r.p = Vec3f{ (g.RandomFloat() - 0.5f) * extent, (g.RandomFloat() - 0.5f) * extent, g.RandomFloat() * extent * 0.5f };
@@ -757,6 +776,8 @@ static void cmdKatTrace(int n, uint64_t seed, float extent)
         float tm = g.RandomFloat() * 2.0f;
         memcpy(&rays[(size_t)i * 6], &r.p.x, 12); memcpy(&rays[(size_t)i * 6 + 3], &r.dir.x, 12);
         tmax[i] = tm;
+        }
+        const float tm = tmax[i];
         HitInfo h{};
         bool hit = renderer.TraceRay(r, h, HIT_FRONT_AND_BACK);
         bool occ = renderer.TraceShadowRay(r, tm, HIT_FRONT_AND_BACK);
@@ -884,7 +905,7 @@ int main(int argc, char **argv)
                 "usage: ref_harness <scene.xml> <outdir> <cmd> [args]\n"
                 "  scene                         dump flattened scene, meshes, BVHs\n"
                 "  render seed min max delta W H [y0 y1]\n"
-                "  kat_rng | kat_trace n seed extent | kat_samplers n seed | kat_paths n seed extent\n"
+                "  kat_rng | kat_trace n seed extent [aimed] | kat_samplers n seed | kat_paths n seed extent\n"
                 "  time threads\n");
         return 1;
     }
@@ -910,7 +931,7 @@ int main(int argc, char **argv)
         cmdRender(strtoull(A(4, "7").c_str(), 0, 0), atoi(A(5, "16").c_str()), atoi(A(6, "16").c_str()), (float)atof(A(7, "0.01").c_str()),
                   atoi(A(8, "0").c_str()), atoi(A(9, "0").c_str()), atoi(A(10, "0").c_str()), atoi(A(11, "0").c_str()));
     else if (cmd == "kat_rng") cmdKatRng();
-    else if (cmd == "kat_trace") cmdKatTrace(atoi(A(4, "4096").c_str()), strtoull(A(5, "1").c_str(), 0, 0), (float)atof(A(6, "40").c_str()));
+    else if (cmd == "kat_trace") cmdKatTrace(atoi(A(4, "4096").c_str()), strtoull(A(5, "1").c_str(), 0, 0), (float)atof(A(6, "40").c_str()), atoi(A(7, "0").c_str()));
     else if (cmd == "kat_samplers") cmdKatSamplers(atoi(A(4, "1024").c_str()), strtoull(A(5, "1").c_str(), 0, 0));
     else if (cmd == "kat_paths") cmdKatPaths(atoi(A(4, "4096").c_str()), strtoull(A(5, "1").c_str(), 0, 0), (float)atof(A(6, "40").c_str()));
 #endif

@@ -1,0 +1,207 @@
+"""Parity at the sizes the headline frame runs at, against outputs of the reference itself.
+
+  * config_c_1m: the 1M-triangle scene (BVH depth 24) at 1920x1080 - a 16-row band of the frame that crosses every
+    object, and 8192 rays aimed at the mesh, both answered by the reference (oracle/make_golden.py --config-c).  The
+    scene is rebuilt here from the generated height field; SHA-256 digests of the reference's own mesh arrays, computed
+    normals and BVH pin the library's OBJ arrays, normal computation and BVH builder at this size.
+  * photons_a_large: photon maps of 36 000 + 17 000 photons (kd-trees 16 and 15 levels tall).
+  * every GPU check also runs in a context whose lanes keep only three stack levels in LDS (RT_LDS_LEVELS=3), so the
+    global overflow levels of the BVH stack and of the kd-tree stack are executed against reference answers.
+"""
+import hashlib
+
+import numpy as np
+import pytest
+
+import oraclelib as O
+from raytracer_amd import abi, lib, scenes
+from test_host_side import check_scene_against_dump, mesh_arrays
+
+PSNR_MIN = 45.0
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def photon_words(a):
+    return np.ascontiguousarray(a).view(np.uint32).reshape(-1, 8)
+
+
+_scene_c = {}
+
+
+def scene_c():
+    """The 1M-triangle scene through the library's own reader and BVH builder (about three seconds, built once)."""
+    if "hs" not in _scene_c:
+        g = O.load_golden("config_c_1m")
+        mesh = scenes.heightfield(int(g["mesh_nx"]), int(g["mesh_ny"]))
+        hs = lib.HostScene.from_string(bytes(g["xml"]).decode())
+        hs.set_mesh("mesh_1m.obj", mesh["v"], mesh["vt"], mesh["f"])
+        _scene_c["hs"], _scene_c["g"] = hs, g
+    return _scene_c["hs"], _scene_c["g"]
+
+
+# ---------------------------------------------------------------- CPU: scene and oracle against the reference
+def test_config_c_scene_equals_the_references():
+    hs, g = scene_c()
+    check_scene_against_dump(hs, g)
+    m = hs.desc.meshes[0]
+    a = mesh_arrays(m)
+    a["bvh_nodes"] = a["bvh_nodes"][1:]
+    for k, arr in a.items():
+        assert len(arr) == int(g["count_mesh0_" + k]), k
+        got = np.frombuffer(hashlib.sha256(np.ascontiguousarray(arr).tobytes()).digest(), np.uint8)
+        assert np.array_equal(got, g["sha256_mesh0_" + k]), f"{k} differs from the reference's array"
+    assert m.nf == 1_000_000 and m.bvh_depth == 24
+
+
+def test_config_c_oracle_band():
+    hs, g = scene_c()
+    seed, mn, mx, w, h, y0, y1 = [int(x) for x in g["params"]]
+    prm = abi.default_params(seed=seed, min_spp=mn, max_spp=mx, delta_max=float(g["delta"]))
+    fr = O.render(hs, prm, w, h, y0=y0, y1=y1)
+    assert set(np.unique(g["object_id"])) == {1, 2, 3, 4}  # mesh, both spheres, floor
+    assert np.array_equal(fr.object_id[y0:y1], g["object_id"]), "primary-hit ids"
+    assert np.array_equal(bits(fr.z[y0:y1]), bits(g["z"])), "z-buffer"
+    assert np.array_equal(bits(fr.linear[y0:y1]), bits(g["linear"])), "linear radiance"
+    assert np.array_equal(fr.rgb[y0:y1], g["rgb"]), "8-bit image"
+
+
+def test_config_c_oracle_rays():
+    hs, g = scene_c()
+    n = 2048  # the per-ray Python loop of the oracle binding is the slow part
+    hits = O.trace(hs, g["kat_rays"][:n])
+    assert np.array_equal(hits["node"], g["kat_id"][:n])
+    assert np.array_equal(bits(hits["z"]), bits(g["kat_hit"][:n, 0]))
+    on_obj = g["kat_id"][:n] >= 0
+    assert np.array_equal(bits(hits["p"][on_obj]), bits(g["kat_hit"][:n][on_obj, 1:4]))
+    assert np.array_equal(bits(hits["n"][on_obj]), bits(g["kat_hit"][:n][on_obj, 4:7]))
+    occ = O.trace_shadow(hs, g["kat_rays"][:n], g["kat_tmax"][:n])
+    assert np.array_equal(occ, g["kat_flags"][:n, 2])
+
+
+def test_large_photon_map_oracle():
+    g = O.load_golden("photons_a_large")
+    s = O.scene_from_golden(g)
+    seed, ng, nc, seg, flags = [int(x) for x in g["params"]]
+    pp = abi.PhotonParams(flags=flags, n_global=ng, n_caustic=nc, max_segments=seg, seed=seed)
+    for which, key in ((abi.RT_MAP_GLOBAL, "global"), (abi.RT_MAP_CAUSTICS, "caustic")):
+        ref_raw = g[f"pm_{key}_raw"]
+        assert len(ref_raw) >= 16384
+        raw, paths = O.photons_emit(s, pp, which)
+        assert paths == int(g["pm_paths"][which])
+        assert np.array_equal(photon_words(raw), ref_raw), f"{key}: emitted photons"
+        tree = O.photon_build(raw)
+        assert np.array_equal(photon_words(tree), g[f"pm_{key}_tree"]), f"{key}: balanced kd-tree"
+        col = 0 if which == abi.RT_MAP_GLOBAL else 3
+        e = O.photon_irradiance(tree, g["pm_query"][:, :3], g["pm_query"][:, 3:], float(g["radius"]))
+        assert np.array_equal(bits(e), bits(g["pm_irradiance"][:, col:col + 3])), f"{key}: irradiance estimates"
+
+
+# ---------------------------------------------------------------- GPU, through the C ABI
+@pytest.fixture(scope="module", params=["default", "lds3"])
+def ctx(request):
+    """A context as the library sets it up, and one whose lanes keep three stack levels in LDS: everything deeper goes
+    through the global overflow levels, which a frame of the 1M-triangle scene reaches by itself only for its
+    deepest walks."""
+    mp = pytest.MonkeyPatch()
+    if request.param == "lds3":
+        mp.setenv("RT_LDS_LEVELS", "3")
+    c = lib.Context(0)
+    mp.undo()
+    yield c
+    c.close()
+
+
+@pytest.mark.gpu
+def test_config_c_rays_vs_reference(ctx):
+    hs, g = scene_c()
+    ctx.upload(hs.desc)
+    hits = ctx.trace(g["kat_rays"])
+    ref_hit = g["kat_flags"][:, 0].astype(bool)
+    assert (g["kat_id"] == 1).sum() > 6000  # most rays end on the mesh
+    assert np.array_equal(hits["node"], g["kat_id"]), "hit node ids"
+    assert np.array_equal(bits(hits["z"]), bits(g["kat_hit"][:, 0])), "z"
+    assert np.array_equal(hits["front"][ref_hit], g["kat_flags"][ref_hit, 1])
+    on_obj = ref_hit & (g["kat_id"] >= 0)
+    assert np.array_equal(bits(hits["p"][on_obj]), bits(g["kat_hit"][on_obj, 1:4])), "hit point"
+    assert np.array_equal(bits(hits["n"][on_obj]), bits(g["kat_hit"][on_obj, 4:7])), "normal"
+    np.testing.assert_allclose(hits["uvw"][on_obj], g["kat_hit"][on_obj, 7:10], rtol=0, atol=2e-6)
+    occ = ctx.trace_shadow(g["kat_rays"], g["kat_tmax"])
+    assert np.array_equal(occ, g["kat_flags"][:, 2]), "shadow rays"
+    brief = ctx.trace_brief(g["kat_rays"])
+    assert np.array_equal(brief["node"], g["kat_id"]) and np.array_equal(bits(brief["t"]), bits(g["kat_hit"][:, 0]))
+    occ2 = ctx.trace_brief(g["kat_rays"], g["kat_tmax"])
+    assert np.array_equal(occ2["node"], g["kat_flags"][:, 2])
+
+
+@pytest.mark.gpu
+def test_config_c_band_vs_reference(ctx):
+    """Rows 416..431 of the 1920x1080 frame: rendered as part of the whole frame's first rows of tiles would take
+    seconds on the oracle but not on the GPU, so the GPU renders the whole frame and the band is compared."""
+    hs, g = scene_c()
+    seed, mn, mx, w, h, y0, y1 = [int(x) for x in g["params"]]
+    ctx.upload(hs.desc)
+    ctx.set_camera(hs.camera, w, h)
+    fr = ctx.render(abi.default_params(seed=seed, min_spp=mn, max_spp=mx, delta_max=float(g["delta"])))
+    assert np.array_equal(fr.object_id[y0:y1], g["object_id"]), "primary-hit ids"
+    assert np.array_equal(bits(fr.z[y0:y1]), bits(g["z"])), "z-buffer"
+    assert np.array_equal(fr.sample_count[y0:y1], g["sample_count"])
+    p = O.psnr(fr.rgb[y0:y1], g["rgb"])
+    assert p >= PSNR_MIN, f"PSNR {p:.2f} dB vs the reference's band"
+    close = np.all(np.abs(fr.linear[y0:y1] - g["linear"]) <= 1e-4 * np.maximum(1.0, np.abs(g["linear"])), axis=-1)
+    assert close.mean() >= 0.97, f"only {close.mean():.4f} of the pixels agree in linear radiance"
+
+
+@pytest.mark.gpu
+def test_small_mesh_goldens_with_this_context(ctx):
+    """The 1024-triangle fixtures again (with three LDS levels their depth-10 BVH overflows too)."""
+    g = O.load_golden("kat_trace_mesh")
+    ctx.upload(O.scene_from_golden(g).desc)
+    hits = ctx.trace(g["kat_rays"])
+    assert np.array_equal(hits["node"], g["kat_id"]) and np.array_equal(bits(hits["z"]), bits(g["kat_hit"][:, 0]))
+    assert np.array_equal(ctx.trace_shadow(g["kat_rays"], g["kat_tmax"]), g["kat_flags"][:, 2])
+    g = O.load_golden("image_mesh_96x54_s8")
+    s = O.scene_from_golden(g)
+    seed, mn, mx, w, h = [int(x) for x in g["params"]]
+    ctx.upload(s.desc)
+    ctx.set_camera(s.camera, w, h)
+    fr = ctx.render(abi.default_params(seed=seed, min_spp=mn, max_spp=mx, delta_max=float(g["delta"])))
+    assert np.array_equal(fr.object_id, g["object_id"]) and np.array_equal(bits(fr.z), bits(g["z"]))
+    assert O.psnr(fr.rgb, g["rgb"]) >= PSNR_MIN
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["photons_a_large", "photons_a_indirect_caustics"])
+def test_photon_maps_vs_reference(ctx, name):
+    g = O.load_golden(name)
+    s = O.scene_from_golden(g)
+    seed, ng, nc, seg, flags = [int(x) for x in g["params"]]
+    pp = abi.PhotonParams(flags=flags, n_global=ng, n_caustic=nc, max_segments=seg, seed=seed)
+    ctx.upload(s.desc)
+    for which, key in ((abi.RT_MAP_GLOBAL, "global"), (abi.RT_MAP_CAUSTICS, "caustic")):
+        ref_raw, ref_tree = g[f"pm_{key}_raw"], g[f"pm_{key}_tree"]
+        got, stored = ctx.photons_emit(pp, which, 0, int(g["pm_paths"][which]), len(ref_raw))
+        assert stored >= len(ref_raw) and len(got) == len(ref_raw)
+        same = (photon_words(got) == ref_raw).all(axis=1)
+        assert same.mean() >= 0.999, f"{key}: only {same.mean():.4f} of the emitted photons are bit-identical"
+        ctx.photons_build(which, ref_raw.view(abi.PHOTON_DTYPE).reshape(-1))
+        assert np.array_equal(photon_words(ctx.photons_download(which)), ref_tree), f"{key}: balanced kd-tree"
+        col = 0 if which == abi.RT_MAP_GLOBAL else 3
+        e = ctx.photons_irradiance(which, g["pm_query"][:, :3], g["pm_query"][:, 3:], float(g["radius"]))
+        assert np.array_equal(bits(e), bits(g["pm_irradiance"][:, col:col + 3])), f"{key}: irradiance estimates"
+
+
+@pytest.mark.gpu
+def test_whitted_photon_image_with_this_context(ctx):
+    g = O.load_golden("whitted_pm_a_64x36_b5")
+    s = O.scene_from_golden(g)
+    seed, mn, mx, w, h, bounces, ng, nc, seg, flags = [int(x) for x in g["params"]]
+    ctx.upload(s.desc)
+    ctx.set_camera(s.camera, w, h)
+    ctx.photons_fill(abi.PhotonParams(flags=flags, n_global=ng, n_caustic=nc, max_segments=seg, seed=seed))
+    fr = ctx.render(abi.default_params(seed=seed, min_spp=mn, max_spp=mx, delta_max=float(g["delta"]), max_bounces=bounces,
+                                       mode=abi.RT_MODE_WHITTED, photon_flags=flags, gather_radius=3.0))
+    assert np.array_equal(fr.object_id, g["object_id"]) and np.array_equal(bits(fr.z), bits(g["z"]))
+    assert O.psnr(fr.rgb, g["rgb"]) >= PSNR_MIN
