@@ -262,6 +262,17 @@ typedef struct rt_hit_brief {
 } rt_hit_brief;
 int rt_trace_brief(rt_ctx *ctx, const float *rays6, const float *t_max, int n, rt_hit_brief *out);
 
+/* rt_trace_brief for callers that cannot allocate device memory (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  All three arrays are DEVICE memory
+ * (t_max may be null; its entries must be >= 0); the answers are those of rt_trace_brief, bit for bit.  The call
+ * makes no hipMalloc / hipFree: the kernel's work queue, counters and the BVH-stack levels beyond LDS live in a
+ * static 32 MiB device array of the library, one per GPU, shared by every context and call on that GPU - calls
+ * that overlap in time on one GPU race.  At most RT_NOALLOC_MAX_RAYS rays per call (RT_ERR_INVALID beyond);
+ * RT_ERR_UNSUPPORTED if the scene's BVH needs more stack than the array holds for one workgroup.  Returns after
+ * the answers are complete (synchronises the context's stream); only kernel_ms of rt_get_counters is updated. */
+#define RT_NOALLOC_MAX_RAYS (1 << 24)
+int rt_trace_brief_noalloc(rt_ctx *ctx, const float *d_rays6, const float *d_t_max, int n, rt_hit_brief *d_out);
+
 /* ---- photon maps: replaces class PhotonMap (src/photonmap.h:38-414) and the emission loops of the
  * project-12 snapshot's main() (project12.zip src/main.cpp:262-470) ---- */
 

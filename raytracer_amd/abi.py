@@ -10,6 +10,7 @@ import numpy as np
 
 RT_OK = 0
 RT_ERR_INVALID, RT_ERR_NO_DEVICE, RT_ERR_HIP, RT_ERR_UNSUPPORTED, RT_ERR_IO, RT_ERR_STATE = -1, -2, -3, -4, -5, -6
+RT_NOALLOC_MAX_RAYS = 1 << 24  # rt_trace_brief_noalloc: rays per call
 RT_PRIM_NONE, RT_PRIM_SPHERE, RT_PRIM_PLANE, RT_PRIM_MESH = 0, 1, 2, 3
 RT_LIGHT_AMBIENT, RT_LIGHT_DIRECT, RT_LIGHT_POINT = 0, 1, 2
 RT_MODE_PATH, RT_MODE_WHITTED = 0, 1

@@ -34,6 +34,26 @@ struct RayListIO {
     RT_DEV void put_shadow(uint32_t e, bool occluded) const { hit[e] = make_float4(occluded ? 1.0f : 0.0f, 0.0f, 0.0f, 0.0f); }
 };
 
+// The same list read and answered in the caller's own formats (six floats per ray, an optional t_max array,
+// rt_hit_brief records): nothing to convert on the host, so an entry point built on it needs no staging buffers.
+struct BriefIO {
+    const float *rays6, *t_max; // t_max null: closest hits
+    rt_hit_brief *out;
+    RT_DEV bool fetch(uint32_t e, float4 &o, float4 &d, bool &any_hit, float &tm) const
+    {
+        const float *r = rays6 + (size_t)e * 6;
+        any_hit = t_max != nullptr;
+        tm = any_hit ? t_max[e] : -1.0f;
+        o = make_float4(r[0], r[1], r[2], tm); d = make_float4(r[3], r[4], r[5], 0.0f);
+        return true;
+    }
+    RT_DEV void put_closest(uint32_t e, float t, int node, uint32_t face, int front, float u, float v) const
+    {
+        out[e] = rt_hit_brief{t, node, face & 0x7FFFFFFFu, front, u, v};
+    }
+    RT_DEV void put_shadow(uint32_t e, bool occluded) const { out[e] = rt_hit_brief{0.0f, occluded ? 1 : 0, 0u, 0, 0.0f, 0.0f}; }
+};
+
 #ifndef RT_RAYS_MIN_WAVES
 #define RT_RAYS_MIN_WAVES 4 // 120 registers, nothing spilled: faster than 6 waves with the walk's temporaries in scratch
 #endif

@@ -42,8 +42,19 @@ struct DeviceBuf {
 
 } // namespace
 
+// ---- scratch of the entry point that allocates nothing (rt_trace_brief_noalloc) ----
+// Everything its kernel needs beyond the caller's rays and answers: the work-queue word, the counters and the
+// levels of the lanes' BVH stacks that do not fit LDS.  One copy per GPU, held until the process ends; the name
+// below is only a host-side handle, the device address comes from hipGetSymbolAddress (rt_init).
+constexpr size_t kStaticQueueOff = 0, kStaticCountersOff = 256, kStaticStackOff = 4096;
+constexpr size_t kStaticStackEntries = (size_t)1 << 22; // eight-byte stack entries: 32 MiB
+constexpr size_t kStaticScratchBytes = kStaticStackOff + kStaticStackEntries * sizeof(uint2);
+static_assert(sizeof(DCounters) <= kStaticStackOff - kStaticCountersOff, "counters overlap the stack area");
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
 struct rt_ctx {
     int device = 0;
+    unsigned char *static_scratch = nullptr; // device address of `scratch` on this context's GPU
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, evk0 = nullptr, evk1 = nullptr;
     std::string error;
@@ -362,6 +373,7 @@ int rt_init(int device, rt_ctx **out)
     if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     for (hipEvent_t *ev : {&ctx->ev0, &ctx->ev1, &ctx->evk0, &ctx->evk1})
         if ((e = hipEventCreate(ev)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipGetSymbolAddress((void **)&ctx->static_scratch, HIP_SYMBOL(scratch))) != hipSuccess) return bail("hipGetSymbolAddress", e);
     if ((e = ctx->d_counters.reserve(sizeof(DCounters))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = ctx->d_next_count.reserve(sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
     // per-lane BVH stacks may need more than the default 64 KiB of LDS per workgroup
@@ -380,6 +392,8 @@ int rt_init(int device, rt_ctx **out)
                           (const void *)k_probe<1>, (const void *)k_probe<2>, (const void *)k_probe<5>,
                           (const void *)k_order_keys<1>, (const void *)k_order_keys<2>, (const void *)k_order_keys<5>,
                           (const void *)k_trace, (const void *)k_trace_shadow, (const void *)k_trace_paths})
+        (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    for (const void *k : {(const void *)k_rays<false, 1, BriefIO>, (const void *)k_rays<false, 2, BriefIO>, (const void *)k_rays<false, 5, BriefIO>})
         (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     for (const void *k : {(const void *)k_photon_paths<false, 1>, (const void *)k_photon_paths<false, 2>, (const void *)k_photon_paths<false, 5>,
                           (const void *)k_photon_paths<true, 1>, (const void *)k_photon_paths<true, 2>, (const void *)k_photon_paths<true, 5>,
@@ -1010,6 +1024,44 @@ int rt_trace_brief(rt_ctx *ctx, const float *rays6, const float *t_max, int n, r
         o.face = ff & 0x7FFFFFFFu; o.front = (int32_t)(ff >> 31); o.u = h[i].w; o.v = hv[i];
     }
     return RT_OK;
+}
+
+int rt_trace_brief_noalloc(rt_ctx *ctx, const float *d_rays6, const float *d_t_max, int n, rt_hit_brief *d_out)
+{
+    if (!ctx) return RT_ERR_INVALID;
+    if (!ctx->have_scene) return ctx->fail(RT_ERR_STATE, "no scene uploaded");
+    if (n < 0 || (n > 0 && (!d_rays6 || !d_out))) return ctx->fail(RT_ERR_INVALID, "bad ray / answer array");
+    if (n > RT_NOALLOC_MAX_RAYS) return ctx->fail(RT_ERR_INVALID, "rt_trace_brief_noalloc takes at most %d rays per call (got %d)", RT_NOALLOC_MAX_RAYS, n);
+    if (n == 0) return RT_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    // the lanes' stack levels beyond LDS live in the static scratch: the grid is cut to what it holds
+    const DScene &S0 = ctx->scene;
+    const size_t ovf_levels = std::max<size_t>(1, (size_t)(S0.stack_levels - S0.lds_levels));
+    const size_t max_blocks = kStaticStackEntries / (ovf_levels * kBlock);
+    if (max_blocks < 1) return ctx->fail(RT_ERR_UNSUPPORTED, "rt_trace_brief_noalloc: %zu stack levels beyond LDS exceed the static scratch", ovf_levels);
+    const void *fn = ctx->ray_levels <= 1 ? (const void *)k_rays<false, 1, BriefIO> : ctx->ray_levels == 2 ? (const void *)k_rays<false, 2, BriefIO> : (const void *)k_rays<false, 5, BriefIO>;
+    const size_t lds = stack_lds_bytes(ctx->scene);
+    int per_cu = 1;
+    HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kBlock, lds));
+    per_cu = std::max(1, std::min(per_cu, 8));
+    const uint64_t want_blocks = ((uint64_t)n + kBlock - 1) / kBlock;
+    const dim3 grid((unsigned)std::min<uint64_t>(std::min<uint64_t>(want_blocks, (uint64_t)ctx->n_cu * per_cu), max_blocks));
+    unsigned char *base = ctx->static_scratch; // never the array's name: that is a host-side stand-in
+    // the array keeps the last call's contents: queue word and counters must start at zero (the stack is written before it is read)
+    HIP_TRY(ctx, hipMemsetAsync(base, 0, kStaticStackOff, s));
+    DScene a_scene = ctx->scene;
+    a_scene.stack_overflow = (uint2 *)(base + kStaticStackOff);
+    BriefIO a_io{d_rays6, d_t_max, d_out};
+    uint32_t a_n = (uint32_t)n;
+    DCounters *a_ctr = (DCounters *)(base + kStaticCountersOff);
+    unsigned long long *a_queue = (unsigned long long *)(base + kStaticQueueOff);
+    void *args[] = {&a_scene, &a_io, &a_n, &a_ctr, &a_queue};
+    HIP_TRY(ctx, hipEventRecord(ctx->evk0, s));
+    HIP_TRY(ctx, hipLaunchKernel(fn, grid, dim3(kBlock), args, lds, s));
+    HIP_TRY(ctx, hipEventRecord(ctx->evk1, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    return batch_time(ctx);
 }
 
 int rt_trace_paths(rt_ctx *ctx, const float *rays6, int n, uint64_t seed, const rt_render_params *prm, float *radiance3)

@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("RT_LIB") or os.path.join(_HERE, "librt_mi355x.so")
 # every symbol include/rt_mi355x.h declares
 SYMBOLS = (
     "rt_abi_version", "rt_init", "rt_shutdown", "rt_last_error", "rt_scene_upload", "rt_camera_set", "rt_render",
-    "rt_trace", "rt_trace_shadow", "rt_trace_brief", "rt_trace_paths", "rt_get_counters", "rt_set_counting",
+    "rt_trace", "rt_trace_shadow", "rt_trace_brief", "rt_trace_brief_noalloc", "rt_trace_paths", "rt_get_counters", "rt_set_counting",
     "rt_scene_load_xml", "rt_scene_from_xml_string", "rt_scene_host_desc", "rt_scene_host_camera",
     "rt_scene_host_free", "rt_scene_host_set_mesh", "rt_bvh_build", "rt_free",
     "rt_photons_emit", "rt_photons_build", "rt_photons_fill", "rt_photons_download", "rt_photons_irradiance",
@@ -53,6 +53,7 @@ def load():
     L.rt_trace.argtypes = [vp, abi.f32p, C.c_int, C.POINTER(abi.Hit)]
     L.rt_trace_shadow.argtypes = [vp, abi.f32p, abi.f32p, C.c_int, abi.i32p]
     L.rt_trace_brief.argtypes = [vp, abi.f32p, abi.f32p, C.c_int, C.POINTER(abi.HitBrief)]
+    L.rt_trace_brief_noalloc.argtypes = [vp, vp, vp, C.c_int, vp]
     L.rt_trace_paths.argtypes = [vp, abi.f32p, C.c_int, C.c_uint64, C.POINTER(abi.RenderParams), abi.f32p]
     L.rt_get_counters.argtypes = [vp, C.POINTER(abi.Counters)]
     L.rt_set_counting.argtypes = [vp, C.c_int]
@@ -228,6 +229,10 @@ class Context:
                                            tm.ctypes.data_as(abi.f32p) if tm is not None else None, len(rays),
                                            C.cast(out.ctypes.data, C.POINTER(abi.HitBrief))))
         return out
+
+    def trace_brief_noalloc(self, d_rays6, d_t_max, n, d_out):
+        """rt_trace_brief_noalloc: device addresses in, nothing allocated by the call."""
+        self._check(self._L.rt_trace_brief_noalloc(self._h, d_rays6, d_t_max or None, n, d_out))
 
     def trace_paths(self, rays, seed, params):
         rays = np.ascontiguousarray(rays, np.float32)
