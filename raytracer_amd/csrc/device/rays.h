@@ -71,7 +71,7 @@ struct BriefIO {
 #define RT_RAYS_REFILL_MIN_LANES 24 // fetch new rays once this many lanes are idle
 #endif
 
-constexpr uint32_t kRayChunk = 256; // rays a wave reserves per queue atomic
+constexpr uint32_t kRayChunk = 256; // rays a wave reserves per queue atomic unless the launch says otherwise
 constexpr uint32_t kNoNode = 0x7FFFFFFFu; // not a data word: an inner node's first child index is far smaller
 
 // One lane's ray and its walk, and the steps a wave takes with them.  Used by k_rays below and by
@@ -273,7 +273,7 @@ template <bool COUNT, int LEVELS, class IO> struct RayWalker {
 
 template <bool COUNT, int LEVELS, class IO>
 __global__ __launch_bounds__(kBlock, RT_RAYS_MIN_WAVES) void k_rays(DScene S, IO io, uint32_t n_rays, DCounters *ctr,
-                                                                  unsigned long long *queue)
+                                                                  unsigned long long *queue, uint32_t ray_chunk)
 {
     extern __shared__ uint32_t lds[];
     const LaneStack st = lane_stack(lds, S);
@@ -299,10 +299,10 @@ __global__ __launch_bounds__(kBlock, RT_RAYS_MIN_WAVES) void k_rays(DScene S, IO
         if (idle != 0 && !exhausted && ((uint32_t)__popcll(idle) >= (uint32_t)RT_RAYS_REFILL_MIN_LANES || !__any(w.in_bvh))) {
             if (chunk_next >= chunk_end) {
                 unsigned long long b = 0;
-                if (lane == 0) b = atomicAdd(queue, (unsigned long long)kRayChunk);
+                if (lane == 0) b = atomicAdd(queue, (unsigned long long)ray_chunk);
                 b = __shfl(b, 0, 64);
                 chunk_next = b < n_rays ? (uint32_t)b : n_rays;
-                chunk_end = b + kRayChunk < n_rays ? (uint32_t)(b + kRayChunk) : n_rays;
+                chunk_end = b + ray_chunk < n_rays ? (uint32_t)(b + ray_chunk) : n_rays;
                 if (chunk_next >= chunk_end) exhausted = true;
             }
             const uint32_t avail = chunk_end - chunk_next;

@@ -1,6 +1,6 @@
 // C ABI of the GPU backend: context, scene upload, frame rendering, batch queries.
 // Host-side control only; the arithmetic lives in device/*.h.
-#include "device/pathsm.h"
+#include "device/wavefront.h"
 #include <hipcub/hipcub.hpp>
 #include "device/whitted.h"
 #include "host/photon_map.h"
@@ -61,7 +61,7 @@ struct rt_ctx {
     bool counting = false;
 
     // scene
-    bool have_scene = false;
+    bool have_scene = false, have_meshes = false;
     DScene scene{};
     DeviceBuf d_nodes, d_meshes, d_materials, d_lights, d_textures;
     std::vector<std::unique_ptr<DeviceBuf>> mesh_bufs;
@@ -74,16 +74,11 @@ struct rt_ctx {
     int chunk_items = 0;      // RT_CHUNK_ITEMS: fixed work-queue chunk of the path kernel (experiments), 0 = chosen per launch
     int order_pixels = -1;    // RT_ORDER: 1 = always deal a frame's pixels expensive-first, 0 = never (tile order), default: for tile shards only
     DeviceBuf d_stack_ovf;
-    // wavefront pipeline: path pool, ray queue, counters {count, alive, pad, pad, head(u64), item(u64)}
-    DeviceBuf d_pool, d_wq_ctr;
-    static constexpr int kMaxPools = 4;
-    hipStream_t pool_stream[kMaxPools] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t pool_event[kMaxPools] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t fork_event = nullptr;
-    int n_pools = 1;              // RT_POOLS: independent path pools in flight, each on its own stream (more were slower)
-    uint32_t pool_max = 1u << 22; // RT_POOL: slots per pool
-    bool use_wavefront = false; // RT_PIPELINE=wave: separate logic / ray-queue kernels
-    bool use_lockstep = true;   // RT_PIPELINE=mega: one whole trace call per lane in lock-step (k_paths); sm: k_path_sm
+    // wavefront pipeline (device/wavefront.h): per-slot path state, the bounce lists, list counts, event pairs around the ray launches
+    DeviceBuf d_wf_state, d_wf_queue[2], d_wf_sh_queue, d_wf_counts;
+    static constexpr int kMaxRayLaunches = 96;
+    hipEvent_t ray_ev[2 * kMaxRayLaunches] = {};
+    int pipeline = -1; // RT_PIPELINE: 0 = lock-step path kernel (k_paths), 1 = wavefront; -1: chosen per scene (wavefront when it has meshes)
     size_t ovf_threads = 0;
     int lds_levels_max = 13;
     int n_cu = 256;
@@ -201,13 +196,8 @@ template <bool TEXBG> const void *paths_kernel_lockstep(bool counting, int ray_l
     return counting ? (const void *)k_paths<true, 5, TEXBG> : (const void *)k_paths<false, 5, TEXBG>;
 }
 
-const void *paths_kernel(bool counting, int ray_levels, bool lockstep, bool textured_background)
+const void *paths_kernel(bool counting, int ray_levels, bool textured_background)
 {
-    if (!lockstep) {
-        if (ray_levels <= 1) return counting ? (const void *)k_path_sm<true, 1> : (const void *)k_path_sm<false, 1>;
-        if (ray_levels == 2) return counting ? (const void *)k_path_sm<true, 2> : (const void *)k_path_sm<false, 2>;
-        return counting ? (const void *)k_path_sm<true, 5> : (const void *)k_path_sm<false, 5>;
-    }
     return textured_background ? paths_kernel_lockstep<true>(counting, ray_levels) : paths_kernel_lockstep<false>(counting, ray_levels);
 }
 
@@ -227,9 +217,9 @@ const void *rays_kernel(bool counting, int ray_levels)
 
 const void *wf_trace_kernel(bool counting, int ray_levels)
 {
-    if (ray_levels <= 1) return counting ? (const void *)k_rays<true, 1, PoolIO> : (const void *)k_rays<false, 1, PoolIO>;
-    if (ray_levels == 2) return counting ? (const void *)k_rays<true, 2, PoolIO> : (const void *)k_rays<false, 2, PoolIO>;
-    return counting ? (const void *)k_rays<true, 5, PoolIO> : (const void *)k_rays<false, 5, PoolIO>;
+    if (ray_levels <= 1) return counting ? (const void *)k_rays<true, 1, WfIO> : (const void *)k_rays<false, 1, WfIO>;
+    if (ray_levels == 2) return counting ? (const void *)k_rays<true, 2, WfIO> : (const void *)k_rays<false, 2, WfIO>;
+    return counting ? (const void *)k_rays<true, 5, WfIO> : (const void *)k_rays<false, 5, WfIO>;
 }
 
 size_t stack_lds_bytes(const DScene &S) { return (size_t)S.lds_levels * kBlock * 8; }
@@ -238,111 +228,84 @@ size_t gather_lds_bytes(const DScene &S) { return stack_lds_bytes(S) + (size_t)k
 
 } // namespace
 
-// Path pool with one slot per thread of the path kernel's grid.
-static int lane_pool(rt_ctx *ctx, uint32_t slots, WfPool &P)
-{
-    const size_t sizes[13] = {16, 16, 16, 16, 8, 16, 16, 8, 16, 16, 16, 4, 4};
-    size_t offs[13], total = 0;
-    for (int i = 0; i < 13; ++i) { offs[i] = total; total += ((size_t)slots * sizes[i] + 255) / 256 * 256; }
-    HIP_TRY(ctx, ctx->d_pool.reserve(total));
-    char *base = ctx->d_pool.as<char>();
-    P.ray_o = (float4 *)(base + offs[0]); P.ray_d = (float4 *)(base + offs[1]); P.thr = (float4 *)(base + offs[2]);
-    P.res = (float4 *)(base + offs[3]); P.rng = (uint2 *)(base + offs[4]); P.meta = (uint4 *)(base + offs[5]);
-    P.hit = (float4 *)(base + offs[6]); P.hit_uv = (float2 *)(base + offs[7]); P.sh_o = (float4 *)(base + offs[8]);
-    P.sh_d = (float4 *)(base + offs[9]); P.contrib = (float4 *)(base + offs[10]); P.vis = (uint32_t *)(base + offs[11]);
-    P.flags = (uint32_t *)(base + offs[12]);
-    P.n_slots = slots;
-    return RT_OK;
-}
-
-// One launch range through the wavefront pipeline.  A pool alternates k_wf_logic (shade, leave rays
-// in the slots, refill from the shared item counter) and k_rays over its slots until none of its
-// slots holds a path.  Several pools run side by side on streams of their own: a ray kernel ends
-// with a tail in which a few long rays keep a few waves busy, and the other pools' kernels fill
-// the machine meanwhile.  The host looks at the alive counts only every few rounds; a round on a
-// pool that has emptied meanwhile does nothing.
-static int render_wavefront(rt_ctx *ctx, const DFrame &F, const int32_t *act, uint64_t items, int k0, int nk,
-                            const FramePlanes &planes, size_t lds)
+// One sampling round of `items` camera paths through the wavefront pipeline (device/wavefront.h): camera rays, then per
+// bounce one ray launch (extension rays of the live paths + shadow rays of the previous bounce) and one shading launch,
+// until no path and no shadow ray is left.  The host reads the two list counts after every shading launch.
+static int render_wavefront(rt_ctx *ctx, const DFrame &F, const int32_t *act, uint64_t items64, int k0, int nk,
+                            const FramePlanes &planes, size_t lds, double *ray_ms, uint32_t *ray_launches)
 {
     hipStream_t s = ctx->stream;
-    const int np = (int)std::min<uint64_t>((uint64_t)ctx->n_pools, std::max<uint64_t>(1, items / (4 * kBlock)));
-    const uint32_t slots = (uint32_t)std::min<uint64_t>(ctx->pool_max, ((items + np - 1) / np + kBlock - 1) / kBlock * kBlock);
-    // pool arrays, 256-byte aligned sub-allocations of one buffer
-    const size_t sizes[13] = {16, 16, 16, 16, 8, 16, 16, 8, 16, 16, 16, 4, 4};
-    size_t offs[13], total = 0;
-    for (int i = 0; i < 13; ++i) { offs[i] = total; total += ((size_t)slots * sizes[i] + 255) / 256 * 256; }
-    HIP_TRY(ctx, ctx->d_pool.reserve(total * np));
-    const dim3 logic_grid((unsigned)std::min<uint64_t>(slots / kBlock, (uint64_t)ctx->n_cu * 6));
-    const size_t ctr_bytes = (64 + (size_t)logic_grid.x * 16 + 255) / 256 * 256; // alive, trace queue word, per-workgroup item ranges
-    HIP_TRY(ctx, ctx->d_wq_ctr.reserve(256 + ctr_bytes * np));
-    unsigned long long *item_counter = ctx->d_wq_ctr.as<unsigned long long>();
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_wq_ctr.p, 0, 256 + ctr_bytes * np, s));
+    const uint32_t items = (uint32_t)items64;
+    // per-slot arrays, 256-byte aligned sub-allocations of one buffer
+    const size_t sizes[9] = {16, 16, 16, 8, 16, 4, 16, 16, 16};
+    size_t offs[9], total = 0;
+    for (int i = 0; i < 9; ++i) { offs[i] = total; total += ((size_t)items * sizes[i] + 255) / 256 * 256; }
+    HIP_TRY(ctx, ctx->d_wf_state.reserve(total));
+    for (auto &q : ctx->d_wf_queue) HIP_TRY(ctx, q.reserve((size_t)items * 4));
+    HIP_TRY(ctx, ctx->d_wf_sh_queue.reserve((size_t)items * 4));
+    HIP_TRY(ctx, ctx->d_wf_counts.reserve(256));
+    char *base = ctx->d_wf_state.as<char>();
+    WfState P;
+    P.ray_o = (float4 *)(base + offs[0]); P.ray_d = (float4 *)(base + offs[1]); P.thr = (float4 *)(base + offs[2]);
+    P.rng = (uint2 *)(base + offs[3]); P.hit = (float4 *)(base + offs[4]); P.hit_v = (float *)(base + offs[5]);
+    P.sh_o = (float4 *)(base + offs[6]); P.sh_d = (float4 *)(base + offs[7]); P.sh_c = (float4 *)(base + offs[8]);
+    P.acc = ctx->d_sbuf.as<float4>();
+
+    const dim3 wide((unsigned)std::min<uint64_t>(((uint64_t)items + kBlock - 1) / kBlock, (uint64_t)ctx->n_cu * 32));
+    hipLaunchKernelGGL(k_wf_generate, wide, dim3(kBlock), 0, s, F, ctx->d_halton.as<float>(), act, items, k0, nk, P);
+    HIP_TRY(ctx, hipGetLastError());
 
     const void *fn = wf_trace_kernel(ctx->counting, ctx->ray_levels);
     int per_cu = 1;
     HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kBlock, lds));
     per_cu = std::max(1, std::min(per_cu, 8));
-    const dim3 trace_grid((unsigned)std::min<uint64_t>((uint64_t)ctx->n_cu * per_cu, (2ull * slots + kBlock - 1) / kBlock));
-    const size_t ovf_stride = std::max<size_t>(1, (size_t)(ctx->scene.stack_levels - ctx->scene.lds_levels)) * ctx->ovf_threads;
-
-    struct Pool { WfPool P; WfQueue Q; char *cb; DScene scene; bool done; uint32_t alive; };
-    Pool pool[rt_ctx::kMaxPools];
-    for (int p = 0; p < np; ++p) {
-        char *base = ctx->d_pool.as<char>() + total * p;
-        WfPool &P = pool[p].P;
-        P.ray_o = (float4 *)(base + offs[0]); P.ray_d = (float4 *)(base + offs[1]); P.thr = (float4 *)(base + offs[2]);
-        P.res = (float4 *)(base + offs[3]); P.rng = (uint2 *)(base + offs[4]); P.meta = (uint4 *)(base + offs[5]);
-        P.hit = (float4 *)(base + offs[6]); P.hit_uv = (float2 *)(base + offs[7]); P.sh_o = (float4 *)(base + offs[8]);
-        P.sh_d = (float4 *)(base + offs[9]); P.contrib = (float4 *)(base + offs[10]); P.vis = (uint32_t *)(base + offs[11]);
-        P.flags = (uint32_t *)(base + offs[12]);
-        P.n_slots = slots;
-        pool[p].cb = ctx->d_wq_ctr.as<char>() + 256 + ctr_bytes * p;
-        pool[p].Q.alive = (uint32_t *)pool[p].cb;
-        pool[p].Q.item = item_counter;
-        pool[p].Q.block_items = (unsigned long long *)(pool[p].cb + 64);
-        pool[p].scene = ctx->scene;
-        pool[p].scene.stack_overflow = ctx->scene.stack_overflow + ovf_stride * p; // ray kernels of different pools overlap in time
-        pool[p].done = false;
-        pool[p].alive = 0;
-    }
-    // the pools' streams start after what the frame's stream has queued so far
-    HIP_TRY(ctx, hipEventRecord(ctx->fork_event, s));
-    for (int p = 0; p < np; ++p) HIP_TRY(ctx, hipStreamWaitEvent(ctx->pool_stream[p], ctx->fork_event, 0));
-
-    uint32_t a_n = 2 * slots;
+    DScene a_scene = ctx->scene;
     DCounters *a_ctr = ctx->d_counters.as<DCounters>();
-    const uint32_t check_every = 8;
-    for (uint32_t iter = 0;; ++iter) {
-        for (int p = 0; p < np; ++p) {
-            if (pool[p].done) continue;
-            hipStream_t ps = ctx->pool_stream[p];
-            HIP_TRY(ctx, hipMemsetAsync(pool[p].cb, 0, 16, ps)); // alive and the ray kernel's queue word; the item counter runs on
-            hipLaunchKernelGGL(k_wf_logic, logic_grid, dim3(kBlock), 0, ps, pool[p].scene, F, ctx->d_halton.as<float>(), act, items, k0, nk,
-                               ctx->d_sbuf.as<float4>(), planes, pool[p].P, pool[p].Q, a_ctr, iter == 0 ? 1 : 0);
+    unsigned long long *a_queue = ctx->d_queue.as<unsigned long long>();
+    uint32_t *counts = ctx->d_wf_counts.as<uint32_t>();
+
+    uint32_t n_ext = items, n_sh = 0;
+    int cur = 0, launch = 0;
+    const uint32_t *queue_in = nullptr; // the camera rays: slot e
+    for (int bounce = 0; n_ext + n_sh > 0; ++bounce) {
+        {   // extension rays of this bounce, shadow rays of the previous one
+            const uint64_t n_rays = (uint64_t)n_ext + n_sh;
+            const dim3 grid((unsigned)std::min<uint64_t>((n_rays + kBlock - 1) / kBlock, (uint64_t)ctx->n_cu * per_cu));
+            WfIO a_io{P, queue_in, ctx->d_wf_sh_queue.as<uint32_t>(), n_ext};
+            uint32_t a_n = (uint32_t)n_rays;
+            // rays a wave reserves at a time: few atomics on the queue word in the large launches, enough chunks for every wave in the small ones
+            const uint64_t per_wave = n_rays / ((uint64_t)grid.x * (kBlock / 64)) / 8;
+            uint32_t a_chunk = per_wave >= 1024 ? 1024u : per_wave >= 512 ? 512u : per_wave >= 256 ? 256u : per_wave >= 128 ? 128u : 64u;
+            void *targs[] = {&a_scene, &a_io, &a_n, &a_ctr, &a_queue, &a_chunk};
+            HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue.p, 0, kQueueBytes, s));
+            const bool timed = launch < rt_ctx::kMaxRayLaunches;
+            if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ray_ev[2 * launch], s));
+            HIP_TRY(ctx, hipLaunchKernel(fn, grid, dim3(kBlock), targs, lds, s));
+            if (timed) { HIP_TRY(ctx, hipEventRecord(ctx->ray_ev[2 * launch + 1], s)); ++launch; }
+        }
+        if (n_ext == 0) break; // those were the last shadow rays
+        HIP_TRY(ctx, hipMemsetAsync(counts, 0, 8, s));
+        {
+            const dim3 grid((unsigned)std::min<uint64_t>(((uint64_t)n_ext + kShadeChunk - 1) / kShadeChunk, (uint64_t)ctx->n_cu * 16));
+            uint32_t *queue_out = ctx->d_wf_queue[cur].as<uint32_t>(), *sh_out = ctx->d_wf_sh_queue.as<uint32_t>();
+            if (bounce == 0) hipLaunchKernelGGL(k_wf_shade<true>, grid, dim3(kBlock), 0, s, a_scene, F, act, k0, nk, P, queue_in, n_ext, queue_out, sh_out, counts, planes);
+            else hipLaunchKernelGGL(k_wf_shade<false>, grid, dim3(kBlock), 0, s, a_scene, F, act, k0, nk, P, queue_in, n_ext, queue_out, sh_out, counts, planes);
             HIP_TRY(ctx, hipGetLastError());
-            PoolIO a_io{pool[p].P};
-            unsigned long long *a_queue = (unsigned long long *)(pool[p].cb + 8);
-            void *targs[] = {&pool[p].scene, &a_io, &a_n, &a_ctr, &a_queue};
-            HIP_TRY(ctx, hipLaunchKernel(fn, trace_grid, dim3(kBlock), targs, lds, ps));
+            queue_in = queue_out;
+            cur ^= 1;
         }
-        if (iter % check_every != check_every - 1) continue;
-        for (int p = 0; p < np; ++p)
-            if (!pool[p].done) HIP_TRY(ctx, hipMemcpyAsync(&pool[p].alive, pool[p].cb, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->pool_stream[p]));
-        bool all_done = true;
-        for (int p = 0; p < np; ++p) {
-            if (pool[p].done) continue;
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->pool_stream[p]));
-            if (pool[p].alive == 0) pool[p].done = true; // no slot holds a path and none could be refilled
-            else all_done = false;
-        }
-        if (all_done) break;
-        if (iter > (1u << 24)) return ctx->fail(RT_ERR_HIP, "wavefront loop did not terminate");
+        uint32_t got[2] = {0, 0};
+        HIP_TRY(ctx, hipMemcpyAsync(got, counts, 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipStreamSynchronize(s));
+        n_ext = got[0]; n_sh = got[1];
     }
-    // the frame's stream goes on after the pools
-    for (int p = 0; p < np; ++p) {
-        HIP_TRY(ctx, hipEventRecord(ctx->pool_event[p], ctx->pool_stream[p]));
-        HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->pool_event[p], 0));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    for (int i = 0; i < launch; ++i) {
+        float ms = 0;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ray_ev[2 * i], ctx->ray_ev[2 * i + 1]));
+        *ray_ms += ms;
     }
+    *ray_launches += (uint32_t)launch;
     return RT_OK;
 }
 
@@ -379,14 +342,12 @@ int rt_init(int device, rt_ctx **out)
     // per-lane BVH stacks may need more than the default 64 KiB of LDS per workgroup
     for (const void *k : {(const void *)k_rays<false, 1, RayListIO>, (const void *)k_rays<false, 2, RayListIO>, (const void *)k_rays<false, 5, RayListIO>,
                           (const void *)k_rays<true, 1, RayListIO>, (const void *)k_rays<true, 2, RayListIO>, (const void *)k_rays<true, 5, RayListIO>,
-                          (const void *)k_path_sm<false, 1>, (const void *)k_path_sm<false, 2>, (const void *)k_path_sm<false, 5>,
-                          (const void *)k_path_sm<true, 1>, (const void *)k_path_sm<true, 2>, (const void *)k_path_sm<true, 5>,
                           (const void *)k_paths<false, 1, false>, (const void *)k_paths<false, 2, false>, (const void *)k_paths<false, 5, false>,
                           (const void *)k_paths<true, 1, false>, (const void *)k_paths<true, 2, false>, (const void *)k_paths<true, 5, false>,
                           (const void *)k_paths<false, 1, true>, (const void *)k_paths<false, 2, true>, (const void *)k_paths<false, 5, true>,
                           (const void *)k_paths<true, 1, true>, (const void *)k_paths<true, 2, true>, (const void *)k_paths<true, 5, true>,
-                          (const void *)k_rays<false, 1, PoolIO>, (const void *)k_rays<false, 2, PoolIO>, (const void *)k_rays<false, 5, PoolIO>,
-                          (const void *)k_rays<true, 1, PoolIO>, (const void *)k_rays<true, 2, PoolIO>, (const void *)k_rays<true, 5, PoolIO>,
+                          (const void *)k_rays<false, 1, WfIO>, (const void *)k_rays<false, 2, WfIO>, (const void *)k_rays<false, 5, WfIO>,
+                          (const void *)k_rays<true, 1, WfIO>, (const void *)k_rays<true, 2, WfIO>, (const void *)k_rays<true, 5, WfIO>,
                           (const void *)k_whitted<false, 1>, (const void *)k_whitted<false, 2>, (const void *)k_whitted<false, 5>,
                           (const void *)k_whitted<true, 1>, (const void *)k_whitted<true, 2>, (const void *)k_whitted<true, 5>,
                           (const void *)k_probe<1>, (const void *)k_probe<2>, (const void *)k_probe<5>,
@@ -402,17 +363,9 @@ int rt_init(int device, rt_ctx **out)
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
     ctx->n_cu = prop.multiProcessorCount;
-    if (const char *e3 = getenv("RT_PIPELINE")) {
-        ctx->use_wavefront = strcmp(e3, "wave") == 0;
-        ctx->use_lockstep = strcmp(e3, "sm") != 0;
-    }
-    if (const char *e4 = getenv("RT_POOL")) ctx->pool_max = (uint32_t)std::max(256, atoi(e4));
-    if (const char *e5 = getenv("RT_POOLS")) ctx->n_pools = std::max(1, std::min((int)rt_ctx::kMaxPools, atoi(e5)));
-    for (int i = 0; i < rt_ctx::kMaxPools; ++i) {
-        if ((e = hipStreamCreateWithFlags(&ctx->pool_stream[i], hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
-        if ((e = hipEventCreateWithFlags(&ctx->pool_event[i], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
-    }
-    if ((e = hipEventCreateWithFlags(&ctx->fork_event, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+    if (const char *e3 = getenv("RT_PIPELINE")) ctx->pipeline = strcmp(e3, "wave") == 0 ? 1 : strcmp(e3, "mega") == 0 ? 0 : -1;
+    for (hipEvent_t &ev : ctx->ray_ev)
+        if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
     if (const char *e8 = getenv("RT_CHUNK_ITEMS")) ctx->chunk_items = std::max(0, atoi(e8)) / 64 * 64;
     if (const char *e7 = getenv("RT_ORDER")) ctx->order_pixels = atoi(e7) != 0 ? 1 : 0;
     if (const char *e2 = getenv("RT_LDS_LEVELS")) ctx->lds_levels_max = std::max(1, std::min(64, atoi(e2))); // tuning knob
@@ -426,11 +379,7 @@ void rt_shutdown(rt_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
-    for (int i = 0; i < rt_ctx::kMaxPools; ++i) {
-        if (ctx->pool_stream[i]) { (void)hipStreamSynchronize(ctx->pool_stream[i]); (void)hipStreamDestroy(ctx->pool_stream[i]); }
-        if (ctx->pool_event[i]) (void)hipEventDestroy(ctx->pool_event[i]);
-    }
-    if (ctx->fork_event) (void)hipEventDestroy(ctx->fork_event);
+    for (hipEvent_t ev : ctx->ray_ev) if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : {ctx->ev0, ctx->ev1, ctx->evk0, ctx->evk1}) if (ev) (void)hipEventDestroy(ev);
     delete ctx;
 }
@@ -613,8 +562,7 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc)
     S.lds_levels = std::min(S.stack_levels, ctx->lds_levels_max);
     const size_t ovf_levels = (size_t)(S.stack_levels - S.lds_levels);
     ctx->ovf_threads = (size_t)ctx->n_cu * 8 * kBlock;
-    // one area per kernel that can be in flight at a time (the wavefront pipeline runs one ray kernel per pool)
-    HIP_TRY(ctx, ctx->d_stack_ovf.reserve(std::max<size_t>(1, ovf_levels) * ctx->ovf_threads * sizeof(uint2) * rt_ctx::kMaxPools));
+    HIP_TRY(ctx, ctx->d_stack_ovf.reserve(std::max<size_t>(1, ovf_levels) * ctx->ovf_threads * sizeof(uint2)));
     S.stack_overflow = ctx->d_stack_ovf.as<uint2>();
 
     HIP_TRY(ctx, ctx->d_nodes.reserve(sizeof(DNode) * nn));
@@ -642,6 +590,7 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc)
     ctx->pmap_flags = -1;
     ctx->scene = S;
     ctx->ray_levels = ray_levels;
+    ctx->have_meshes = max_mesh_depth >= 0;
     ctx->have_scene = true;
     return RT_OK;
 }
@@ -728,6 +677,7 @@ int rt_render(rt_ctx *ctx, const rt_render_params *prm, rt_frame_out *out)
     const size_t lds = gathers ? gather_lds_bytes(ctx->scene) : stack_lds_bytes(ctx->scene);
     double trace_ms = 0.0;
     uint32_t launches = 0;
+    uint64_t wf_paths = 0; // camera paths of the wavefront pipeline (its kernels count rays only)
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, s));
 
     // Expensive pixels first (path frames): keys from one camera ray per pixel, then a stable descending radix sort.
@@ -759,7 +709,11 @@ int rt_render(rt_ctx *ctx, const rt_render_params *prm, rt_frame_out *out)
 
     // sampling rounds: the first takes min_spp samples of every pixel, later ones
     // up to 16 more of the pixels the stop test has not released yet
-    const uint64_t kMaxItems = 1ull << 28; // bounds the sample buffer to 4 GiB
+    // path frames of scenes with meshes go through the wavefront pipeline (ray-level regeneration keeps the waves of the
+    // BVH walk full); scenes of spheres and planes, where every ray costs the same, through the lock-step path kernel
+    const bool has_mesh = ctx->have_meshes;
+    const bool wavefront = prm->mode == RT_MODE_PATH && prm->max_bounces > 0 && (ctx->pipeline == 1 || (ctx->pipeline < 0 && has_mesh));
+    const uint64_t kMaxItems = wavefront ? 1ull << 27 : 1ull << 28; // bounds the sample buffer to 4 GiB (the wavefront's path state to 18 GiB)
     uint32_t n_active = n0;
     int cur = 0, k0 = 0;
     while (n_active > 0 && k0 < prm->max_spp) {
@@ -794,7 +748,7 @@ int rt_render(rt_ctx *ctx, const rt_render_params *prm, rt_frame_out *out)
                 unsigned long long *a_queue = ctx->d_queue.as<unsigned long long>();
                 void *args[] = {&a_scene, &F, &a_hal, &act, &a_items, &a_k0, &a_nk, &a_sbuf, &P, &a_ctr, &a_queue};
                 HIP_TRY(ctx, hipLaunchKernel(fn, grid, dim3(kBlock), args, lds, s));
-            } else if (prm->max_bounces <= 0 && ctx->use_lockstep && !ctx->use_wavefront) {
+            } else if (prm->max_bounces <= 0) {
                 const void *fn = ctx->ray_levels <= 1 ? (const void *)k_probe<1> : ctx->ray_levels == 2 ? (const void *)k_probe<2> : (const void *)k_probe<5>;
                 const dim3 grid((unsigned)std::min<uint64_t>((items + kBlock - 1) / kBlock, ctx->ovf_threads / kBlock));
                 DScene a_scene = ctx->scene;
@@ -805,8 +759,9 @@ int rt_render(rt_ctx *ctx, const rt_render_params *prm, rt_frame_out *out)
                 DCounters *a_ctr = ctx->d_counters.as<DCounters>();
                 void *args[] = {&a_scene, &F, &a_hal, &act, &a_items, &a_k0, &a_nk, &a_sbuf, &P, &a_ctr};
                 HIP_TRY(ctx, hipLaunchKernel(fn, grid, dim3(kBlock), args, lds, s));
-            } else if (ctx->use_wavefront) {
-                if (int rc = render_wavefront(ctx, F, act, items, k0, nk, P, lds)) return rc;
+            } else if (wavefront) {
+                if (int rc = render_wavefront(ctx, F, act, items, k0, nk, P, lds, &trace_ms, &launches)) return rc;
+                wf_paths += items;
             } else {
             // persistent launch: as many workgroups as the chip holds at once (more would only queue up)
             {
@@ -819,7 +774,7 @@ int rt_render(rt_ctx *ctx, const rt_render_params *prm, rt_frame_out *out)
                 F.chunk = per_wave >= 1024 ? 1024u : per_wave >= 512 ? 512u : 256u;
                 if (ctx->chunk_items > 0) F.chunk = (uint32_t)ctx->chunk_items;
             }
-            const void *fn = paths_kernel(ctx->counting, ctx->ray_levels, ctx->use_lockstep, ctx->scene.background_texture > 0);
+            const void *fn = paths_kernel(ctx->counting, ctx->ray_levels, ctx->scene.background_texture > 0);
             int per_cu = 1;
             HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kBlock, lds));
             per_cu = std::max(1, std::min(per_cu, 8));
@@ -834,15 +789,8 @@ int rt_render(rt_ctx *ctx, const rt_render_params *prm, rt_frame_out *out)
                 float4 *a_sbuf = ctx->d_sbuf.as<float4>();
                 DCounters *a_ctr = ctx->d_counters.as<DCounters>();
                 unsigned long long *a_queue = ctx->d_queue.as<unsigned long long>();
-                if (ctx->use_lockstep) {
-                    void *args[] = {&a_scene, &F, &a_hal, &act, &a_items, &a_k0, &a_nk, &a_sbuf, &P, &a_ctr, &a_queue};
-                    HIP_TRY(ctx, hipLaunchKernel(fn, grid, dim3(kBlock), args, lds, s));
-                } else {
-                    WfPool pool;
-                    if (int rc = lane_pool(ctx, grid.x * kBlock, pool)) return rc;
-                    void *args[] = {&a_scene, &F, &a_hal, &act, &a_items, &a_k0, &a_nk, &a_sbuf, &P, &pool, &a_ctr, &a_queue};
-                    HIP_TRY(ctx, hipLaunchKernel(fn, grid, dim3(kBlock), args, lds, s));
-                }
+                void *args[] = {&a_scene, &F, &a_hal, &act, &a_items, &a_k0, &a_nk, &a_sbuf, &P, &a_ctr, &a_queue};
+                HIP_TRY(ctx, hipLaunchKernel(fn, grid, dim3(kBlock), args, lds, s));
             }
             }
             HIP_TRY(ctx, hipGetLastError());
@@ -851,11 +799,13 @@ int rt_render(rt_ctx *ctx, const rt_render_params *prm, rt_frame_out *out)
                                ctx->d_sbuf.as<float4>(), ctx->d_state.as<PixelState>(), P,
                                ctx->d_active[cur ^ 1].as<int32_t>(), ctx->d_next_count.as<uint32_t>());
             HIP_TRY(ctx, hipGetLastError());
-            HIP_TRY(ctx, hipEventSynchronize(ctx->evk1));
-            float ms = 0;
-            HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->evk0, ctx->evk1));
-            trace_ms += ms;
-            ++launches;
+            if (!wavefront) { // the wavefront pipeline times its own ray launches
+                HIP_TRY(ctx, hipEventSynchronize(ctx->evk1));
+                float ms = 0;
+                HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->evk0, ctx->evk1));
+                trace_ms += ms;
+                ++launches;
+            }
         }
         uint32_t next = 0;
         HIP_TRY(ctx, hipMemcpyAsync(&next, ctx->d_next_count.p, sizeof next, hipMemcpyDeviceToHost, s));
@@ -889,7 +839,7 @@ int rt_render(rt_ctx *ctx, const rt_render_params *prm, rt_frame_out *out)
     float ms = 0;
     HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     rt_counters &c = ctx->counters;
-    c.closest_rays = dc.closest; c.shadow_rays = dc.shadow; c.camera_paths = dc.paths;
+    c.closest_rays = dc.closest; c.shadow_rays = dc.shadow; c.camera_paths = dc.paths + wf_paths;
     c.box_tests = dc.box_tests; c.tri_tests = dc.tri_tests;
     c.gathers = dc.gathers; c.photon_visits = dc.photon_visits;
     for (int i = 0; i < 16; ++i) c.phase_cycles[i] = dc.phase[i];
@@ -997,7 +947,8 @@ int rt_trace_brief(rt_ctx *ctx, const float *rays6, const float *t_max, int n, r
         uint32_t a_n = (uint32_t)n;
         DCounters *a_ctr = ctx->d_counters.as<DCounters>();
         unsigned long long *a_queue = ctx->d_queue.as<unsigned long long>();
-        void *args[] = {&a_scene, &a_io, &a_n, &a_ctr, &a_queue};
+        uint32_t a_chunk = kRayChunk;
+        void *args[] = {&a_scene, &a_io, &a_n, &a_ctr, &a_queue, &a_chunk};
         HIP_TRY(ctx, hipEventRecord(ctx->evk0, s));
         HIP_TRY(ctx, hipLaunchKernel(fn, grid, dim3(kBlock), args, lds, s));
         HIP_TRY(ctx, hipEventRecord(ctx->evk1, s));
@@ -1056,7 +1007,8 @@ int rt_trace_brief_noalloc(rt_ctx *ctx, const float *d_rays6, const float *d_t_m
     uint32_t a_n = (uint32_t)n;
     DCounters *a_ctr = (DCounters *)(base + kStaticCountersOff);
     unsigned long long *a_queue = (unsigned long long *)(base + kStaticQueueOff);
-    void *args[] = {&a_scene, &a_io, &a_n, &a_ctr, &a_queue};
+    uint32_t a_chunk = kRayChunk;
+    void *args[] = {&a_scene, &a_io, &a_n, &a_ctr, &a_queue, &a_chunk};
     HIP_TRY(ctx, hipEventRecord(ctx->evk0, s));
     HIP_TRY(ctx, hipLaunchKernel(fn, grid, dim3(kBlock), args, lds, s));
     HIP_TRY(ctx, hipEventRecord(ctx->evk1, s));
@@ -1109,7 +1061,7 @@ int ensure_stack_levels(rt_ctx *ctx, int levels)
     // four workgroups of the lookup kernels share a CU's 160 KiB: 20 eight-byte entries per thread, the heap tops included
     S.lds_levels = std::min(S.stack_levels, std::min(ctx->lds_levels_max, 19 - (int)kHeapLds));
     const size_t ovf_levels = (size_t)(S.stack_levels - S.lds_levels);
-    HIP_TRY(ctx, ctx->d_stack_ovf.reserve(std::max<size_t>(1, ovf_levels) * ctx->ovf_threads * sizeof(uint2) * rt_ctx::kMaxPools));
+    HIP_TRY(ctx, ctx->d_stack_ovf.reserve(std::max<size_t>(1, ovf_levels) * ctx->ovf_threads * sizeof(uint2)));
     S.stack_overflow = ctx->d_stack_ovf.as<uint2>();
     return RT_OK;
 }

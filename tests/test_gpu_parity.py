@@ -332,11 +332,11 @@ def test_whitted_photon_images_vs_reference(ctx, name):
 
 
 def test_pipelines_agree(monkeypatch):
-    """The lock-step path kernel (default), the wavefront pipeline (logic kernel + ray-list kernel) and
-    the fused path kernel (ray-level regeneration in one launch) run the same per-path arithmetic:
-    every output plane and the ray counts must be identical."""
+    """The lock-step path kernel and the wavefront pipeline (ray-list kernel with ray-level regeneration + shading
+    kernel, compacted lists between them) run the same per-path arithmetic: every output plane and the ray counts
+    must be identical, whichever of the two a scene gets by default."""
     ctxs = {}
-    for mode in ("mega", "wave", "sm"):
+    for mode in ("mega", "wave"):
         monkeypatch.setenv("RT_PIPELINE", mode)
         ctxs[mode] = lib.Context(0)
     monkeypatch.delenv("RT_PIPELINE")
@@ -350,7 +350,7 @@ def test_pipelines_agree(monkeypatch):
                 frames[mode] = render_gpu(c, s, prm, w, h)
                 k = c.counters()
                 counts[mode] = (k.closest_rays, k.shadow_rays, k.camera_paths)
-            for other in ("wave", "sm"):
+            for other in ("wave",):
                 for plane in ("rgb", "z", "sample_count", "object_id"):
                     assert np.array_equal(getattr(frames["mega"], plane), getattr(frames[other], plane)), (name, other, plane)
                 assert np.array_equal(bits(frames["mega"].linear), bits(frames[other].linear)), (name, other)
