@@ -126,7 +126,8 @@ RT_DEV Ray camera_ray(const DFrame &F, const float *halton, int i, int j, int k,
 constexpr uint32_t kChunk = RT_CHUNK;
 constexpr uint32_t kQueues = RT_QUEUES;
 constexpr uint32_t kQueueStride = 16; // unsigned long longs between queue words (128 bytes)
-constexpr size_t kQueueBytes = kQueues * kQueueStride * sizeof(unsigned long long);
+constexpr uint32_t kMaxRayParts = 8; // parts of a ray list (k_rays), one queue word each
+constexpr size_t kQueueBytes = (kQueues > kMaxRayParts ? kQueues : kMaxRayParts) * kQueueStride * sizeof(unsigned long long);
 
 struct WorkQueue {
     unsigned long long *words;
@@ -159,9 +160,6 @@ struct WorkQueue {
     }
 };
 
-#ifndef RT_RESUMABLE_WALKS
-#define RT_RESUMABLE_WALKS 0 // 1: closest-hit walks of k_paths can be put down and taken up again (WalkState); measured slower, see trace.h
-#endif
 #ifndef RT_PATHS_MIN_WAVES
 #define RT_PATHS_MIN_WAVES 6 // waves per SIMD the register allocator must leave room for
 #endif
@@ -188,9 +186,6 @@ __global__ __launch_bounds__(kBlock, RT_PATHS_MIN_WAVES) void k_paths(DScene S, 
     int pix = 0, k = 0;
     float fz = FLT_MAX; int fid = -1;
     PathState ps;
-#if RT_RESUMABLE_WALKS
-    WalkState ws;
-#endif
     path_begin(ps, Ray{mk(0, 0, 0), mk(0, 0, 1)});
     ps.rng.state = 0; ps.rng.inc = 1;
 
@@ -227,11 +222,7 @@ __global__ __launch_bounds__(kBlock, RT_PATHS_MIN_WAVES) void k_paths(DScene S, 
         }
         pt.tock(4);
         if (alive) {
-#if RT_RESUMABLE_WALKS
-            if (!path_step<COUNT, LEVELS, TEXBG, true>(S, F, ps, st, pt, tl, &fz, &fid, &ws)) {
-#else
             if (!path_step<COUNT, LEVELS, TEXBG>(S, F, ps, st, pt, tl, &fz, &fid)) {
-#endif
                 if (k == 0) {
                     if (out.z) out.z[pix] = fz;
                     if (out.object_id) out.object_id[pix] = fid;

@@ -2,13 +2,20 @@
 // with ray-level regeneration: a lane that finishes its ray takes the next one from
 // the list at once, so the lanes of a wave stay busy although rays need anything from
 // 3 to 60 BVH node visits (src/main.cpp:16-125, src/TriObj.cpp:12-229).  The lane
-// carries nothing but the ray and its walk, so the kernel runs at high occupancy.
+// carries nothing but its walk, so the kernel runs at high occupancy: while a ray is
+// inside a mesh the lane keeps the ray in the mesh's space only; when it comes out, the
+// world-space ray is read again from the list.
 //
 // Where rays come from and where answers go is a policy (IO): a plain list for the batch
-// query entry point (RayListIO below), the path pool of the wavefront renderer (wavefront.h).
-//   bool fetch(e, o, d, any_hit, t_max)   entry e of the list; false = no ray there
-//   void put_closest(e, t, node, face, front, u, v)   t = FLT_MAX, node = -1: nothing hit
-//   void put_shadow(e, occluded)
+// query entry points (RayListIO, BriefIO below), the path state of the wavefront renderer (wavefront.h).
+//   bool fetch(e, o, d, any_hit, t_max, tag)   entry e of the list; false = no ray there.  tag is what
+//                                              the lane keeps of the entry (whatever the other calls need)
+//   void refetch(tag, any_hit, o, d)           the same ray again
+//   void put_closest(tag, t, node, face, front, u, v)   t = FLT_MAX, node = -1: nothing hit
+//   void put_shadow(tag, occluded)
+//   kDeferShadow, Pending, begin_put_shadow(tag, pending), end_put_shadow(tag, pending): an IO that has to read
+//   something before it can take the answer "not occluded" splits the hand-over into its loads and its stores; the
+//   kernel issues the loads, then the loads of the lane's next ray, and only then asks for the stores
 #pragma once
 #include "kernels.h"
 
@@ -16,16 +23,22 @@ namespace rtd {
 
 // ray_o = origin xyz, w = t_max for an any-hit (shadow) ray, negative for a closest-hit ray; ray_d = direction
 // hit = closest: (t, node id bits, face | front << 31, u), hit_v = v;  any-hit: (1 or 0, 0, 0, 0)
+struct NoPending {};
 struct RayListIO {
+    static constexpr bool kDeferShadow = false;
+    typedef NoPending Pending;
+    RT_DEV void begin_put_shadow(uint32_t, Pending &) const {}
+    RT_DEV void end_put_shadow(uint32_t, const Pending &) const {}
     const float4 *ray_o, *ray_d;
     float4 *hit;
     float *hit_v;
-    RT_DEV bool fetch(uint32_t e, float4 &o, float4 &d, bool &any_hit, float &t_max) const
+    RT_DEV bool fetch(uint32_t e, float4 &o, float4 &d, bool &any_hit, float &t_max, uint32_t &tag) const
     {
         o = ray_o[e]; d = ray_d[e];
-        any_hit = !(o.w < 0.0f); t_max = o.w;
+        any_hit = !(o.w < 0.0f); t_max = o.w; tag = e;
         return true;
     }
+    RT_DEV void refetch(uint32_t e, bool, float4 &o, float4 &d) const { o = ray_o[e]; d = ray_d[e]; }
     RT_DEV void put_closest(uint32_t e, float t, int node, uint32_t face, int front, float u, float v) const
     {
         hit[e] = make_float4(t, __uint_as_float((uint32_t)node), __uint_as_float(face | ((uint32_t)front << 31)), u);
@@ -37,14 +50,23 @@ struct RayListIO {
 // The same list read and answered in the caller's own formats (six floats per ray, an optional t_max array,
 // rt_hit_brief records): nothing to convert on the host, so an entry point built on it needs no staging buffers.
 struct BriefIO {
+    static constexpr bool kDeferShadow = false;
+    typedef NoPending Pending;
+    RT_DEV void begin_put_shadow(uint32_t, Pending &) const {}
+    RT_DEV void end_put_shadow(uint32_t, const Pending &) const {}
     const float *rays6, *t_max; // t_max null: closest hits
     rt_hit_brief *out;
-    RT_DEV bool fetch(uint32_t e, float4 &o, float4 &d, bool &any_hit, float &tm) const
+    RT_DEV void refetch(uint32_t e, bool, float4 &o, float4 &d) const
     {
         const float *r = rays6 + (size_t)e * 6;
+        o = make_float4(r[0], r[1], r[2], 0.0f); d = make_float4(r[3], r[4], r[5], 0.0f);
+    }
+    RT_DEV bool fetch(uint32_t e, float4 &o, float4 &d, bool &any_hit, float &tm, uint32_t &tag) const
+    {
         any_hit = t_max != nullptr;
         tm = any_hit ? t_max[e] : -1.0f;
-        o = make_float4(r[0], r[1], r[2], tm); d = make_float4(r[3], r[4], r[5], 0.0f);
+        refetch(e, any_hit, o, d);
+        tag = e;
         return true;
     }
     RT_DEV void put_closest(uint32_t e, float t, int node, uint32_t face, int front, float u, float v) const
@@ -74,37 +96,43 @@ struct BriefIO {
 constexpr uint32_t kRayChunk = 256; // rays a wave reserves per queue atomic unless the launch says otherwise
 constexpr uint32_t kNoNode = 0x7FFFFFFFu; // not a data word: an inner node's first child index is far smaller
 
-// One lane's ray and its walk, and the steps a wave takes with them.  Used by k_rays below and by
-// the path kernel (pathsm.h); the members live in registers.
+// One lane's ray and its walk, and the steps a wave takes with them; the members live in registers.
 template <bool COUNT, int LEVELS, class IO> struct RayWalker {
+    // The walk goes through the four-wide form of the BVH (DScene::bvh4_pool): one 128-byte record gives the boxes of a
+    // node's grandchildren, the ones the ray enters are taken nearest first.  Half the dependent fetches of the binary
+    // walk, the same triangles: a leaf is reached if and only if the ray enters every box above it, and a box lies
+    // inside its parent's.  What can differ from the reference's order is which of several triangles hit at exactly the
+    // same distance is reported; t and the node never do.  The counting variant walks the binary tree, as the reference
+    // does: its box and triangle counts are the reference's.
+    static constexpr bool kWide = !COUNT;
     bool active = false, any_hit = false, in_bvh = false;
-    uint32_t ray_i = 0;
-    Ray wray{mk(0, 0, 0), mk(0, 0, 1)}; // world space
+    bool unoccluded = false;             // a finished shadow ray whose answer the IO has not been told yet (retire())
+    uint32_t tag = 0;                    // the list entry as the IO names it
+    Ray wray{mk(0, 0, 0), mk(0, 0, 1)};  // world space
     float t_max = 0.0f;
     int node_i = 0;                      // scene node being visited
-    RayLevels<LEVELS> lv;                // local rays of the hierarchy levels above it
     float best_t = FLT_MAX; int best_node = -1, best_front = 1; uint32_t best_face = 0; float best_u = 0, best_v = 0;
-    Ray lr{mk(0, 0, 0), mk(0, 0, 1)}; V3 inv = mk(0, 0, 0); bool exact = false;
-    GF4 bvh = nullptr, tris = nullptr;
+    Ray lr{mk(0, 0, 0), mk(0, 0, 1)}; V3 inv = mk(0, 0, 0); bool exact = false; // the ray in the space of the mesh it is in
     int sp = 0; float t_limit = 0.0f;
     bool m_hit = false; uint32_t m_face = 0; float m_u = 0, m_v = 0, m_det = 0;
     bool at_leaf = false; uint32_t leaf_data = 0, leaf_i = 0;
     uint32_t cur = kNoNode; // node to visit next (its data word), kNoNode: take one from the stack
 
-
-
-    RT_DEV void start(uint32_t e, float4 o, float4 d, bool shadow, float tmax, PathTally &pt)
+    RT_DEV void start(uint32_t tg, float4 o, float4 d, bool shadow, float tmax, PathTally &pt)
     {
-        ray_i = e;
+        tag = tg;
         wray.p = mk(o.x, o.y, o.z); wray.d = mk(d.x, d.y, d.z);
         any_hit = shadow; t_max = tmax;
         if (any_hit) ++pt.shadow; else ++pt.closest;
         node_i = 0; in_bvh = false; active = true;
         best_t = FLT_MAX; best_node = -1; best_front = 1; best_face = 0; best_u = 0; best_v = 0;
     }
+    // A shadow ray's answer is handed over when the lane takes its next ray (retire(), called by the refill step): what
+    // the IO has to read for it then travels together with the next ray's data instead of holding the wave up here.
     RT_DEV void shadow_done(const IO &io, bool occluded)
     {
-        io.put_shadow(ray_i, occluded);
+        if (IO::kDeferShadow) unoccluded = !occluded;
+        else io.put_shadow(tag, occluded);
         active = false;
     }
 
@@ -113,51 +141,69 @@ template <bool COUNT, int LEVELS, class IO> struct RayWalker {
     RT_DEV void phases(const DScene &S, const IO &io, const LaneStack &st, PathTally &pt, Tally<COUNT> &tl)
     {
         const float epsilon = 1e-6f;
+        const GF4 bvh = (GF4)S.bvh_pool, tris = (GF4)S.tri_pool;
     // ================= scene-graph steps of rays that are not inside a mesh (main.cpp:16-89) =================
-    // One pass over the node list in step: the node index is wave-uniform, so node matrices arrive
-    // through scalar loads; a lane takes part from the node it has got to, and stays in the pass
-    // until it enters a mesh or runs off the end of the list.
+    // One pass over the node list in step: the node index is wave-uniform, so a node's record arrives through one
+    // scalar fetch; a lane takes part from the node it has got to (the local rays of the hierarchy levels above it
+    // are rebuilt on the way there), and stays in the pass until it enters a mesh or runs off the end of the list.
     const uint64_t stepping = __ballot(active && !in_bvh);
     if (stepping != 0 && ((uint32_t)__popcll(stepping) >= (uint32_t)RT_RAYS_SCENE_MIN_LANES || !__any(in_bvh))) {
         pt.tock(12);
+        const bool mine = active && !in_bvh;
+        const int first = node_i;
+        RayLevels<LEVELS> lv;
+        lv.init(wray);
+        // An object whose padded world-space box the ray does not reach before its closest hit so far (t is the same
+        // in every node's space) cannot change the answer: the lane skips it, and a node no lane of the wave has
+        // business with costs the wave nothing but this test.  The reference tests every object (it keeps the boxes,
+        // src/scene.h:434-444, but never looks at them).
+        const V3 winv = cull_inverse(wray.d);
         for (int n = 0; n < S.n_nodes; ++n) {
-            if (!__any(active && !in_bvh && node_i == n)) continue;
-            const DNode &nd = S.nodes[n];
-            if (active && !in_bvh && node_i == n) {
-                const int d = nd.depth;
+            const TNode &nd = S.tnodes[n];
+            const uint32_t meta = nd.meta;
+            const int prim = (int)(meta & 0xFFu), d = (int)((meta >> 8) & 0xFFu);
+            const bool has_children = (meta >> 16) != 0;
+            bool here = mine && active && !in_bvh; // still in the pass
+            // (the counting variant takes every object, as the reference does: its box and triangle tests are the reference's)
+            const bool wanted = here && n >= first && prim != RT_PRIM_NONE && (COUNT || reaches_box(nd.wbox, wray.p, winv, any_hit ? t_max : best_t));
+            if (here && n >= first && !wanted) node_i = n + 1; // nothing to do at this node
+            if (!has_children) here = wanted;
+            if (!__any(here)) continue;
+            if (here) {
                 const Ray parent = (d == 0) ? wray : lv.get(d - 1);
-                lr = to_node(nd, parent);
-                if (nd.has_children) lv.set(d, lr);
-                const int prim = nd.prim;
-                bool advance = true;
-                if (prim == RT_PRIM_SPHERE || prim == RT_PRIM_PLANE) {
-                    if (any_hit) {
-                        const bool occ = prim == RT_PRIM_SPHERE ? sphere_shadow(lr, t_max) : plane_shadow(lr, t_max);
-                        if (occ) { shadow_done(io, true); advance = false; }
-                    } else {
-                        float t = 0; int front = 1;
-                        const bool ok = prim == RT_PRIM_SPHERE ? sphere_t(lr, t, front) : plane_t(lr, t, front);
-                        if (ok && t < best_t) { best_t = t; best_node = n; best_front = front; best_face = 0; best_u = 0; best_v = 0; }
+                Ray l;
+                l.p = m34_mul(nd.itm, parent.p);
+                l.d = m3_mul(nd.itm, parent.d);
+                if (has_children) lv.set(d, l);
+                if (wanted) {
+                    bool advance = true;
+                    if (prim == RT_PRIM_SPHERE || prim == RT_PRIM_PLANE) {
+                        if (any_hit) {
+                            const bool occ = prim == RT_PRIM_SPHERE ? sphere_shadow(l, t_max) : plane_shadow(l, t_max);
+                            if (occ) { shadow_done(io, true); advance = false; }
+                        } else {
+                            float t = 0; int front = 1;
+                            const bool ok = prim == RT_PRIM_SPHERE ? sphere_t(l, t, front) : plane_t(l, t, front);
+                            if (ok && t < best_t) { best_t = t; best_node = n; best_front = front; best_face = 0; best_u = 0; best_v = 0; }
+                        }
+                    } else if (prim == RT_PRIM_MESH) {
+                        const V3 iv = mk(1.0f / l.d.x, 1.0f / l.d.y, 1.0f / l.d.z);
+                        const bool ex = needs_exact_slabs(l.p, iv);
+                        const float lim = any_hit ? t_max : FLT_MAX;
+                        const f4 r0 = {nd.box[0], nd.box[1], nd.box[2], nd.box[3]}, r1 = {nd.box[4], nd.box[5], 0.0f, 0.0f};
+                        float dist;
+                        tl.boxes(1);
+                        if (bvh_box(ex, l.p, iv, lim, r0, r1, dist)) {
+                            lr = l; inv = iv; exact = ex; t_limit = lim; m_hit = false;
+                            cur = kWide ? nd.root4 : nd.root; // the root is the node to visit next; the stack is empty
+                            sp = 0; in_bvh = true; advance = false;
+                        }
                     }
-                } else if (prim == RT_PRIM_MESH) {
-                    const DMesh &M = S.meshes[nd.mesh];
-                    bvh = (GF4)M.bvh; tris = (GF4)M.tris;
-                    inv = mk(1.0f / lr.d.x, 1.0f / lr.d.y, 1.0f / lr.d.z);
-                    exact = needs_exact_slabs(lr.p, inv);
-                    t_limit = any_hit ? t_max : FLT_MAX;
-                    m_hit = false;
-                    const f4 r0 = bvh[2], r1 = bvh[3];
-                    float dist;
-                    tl.boxes(1);
-                    if (bvh_box(exact, lr.p, inv, t_limit, r0, r1, dist)) {
-                        cur = __float_as_uint(r1.z); // the root is the node to visit next; the stack is empty
-                        sp = 0; in_bvh = true; advance = false;
-                    }
+                    if (advance) node_i = n + 1;
                 }
-                if (advance) node_i = n + 1;
             }
         }
-        if (active && !in_bvh && node_i >= S.n_nodes) {
+        if (mine && active && !in_bvh) { // ran off the end of the node list
             if (any_hit) shadow_done(io, false); // nothing in the way
             else {
                 // closest ray: the spherical lights last (main.cpp:52-70, lights.h:129-156), front side only
@@ -165,8 +211,9 @@ template <bool COUNT, int LEVELS, class IO> struct RayWalker {
                     const rt_light &L = S.lights[l];
                     if (L.type != RT_LIGHT_POINT) continue;
                     Ray r;
-                    r.p = (wray.p - ld3(L.position)) / L.size;
-                    r.d = wray.d / L.size;
+                    r.p = wray.p - ld3(L.position);
+                    r.d = wray.d;
+                    if (L.size != 1.0f) { r.p = r.p / L.size; r.d = r.d / L.size; } // x / 1 is x
                     const float a = dot(r.d, r.d);
                     const float b = 2 * dot(r.d, r.p);
                     const float c = dot(r.p, r.p) - 1.0f;
@@ -178,7 +225,7 @@ template <bool COUNT, int LEVELS, class IO> struct RayWalker {
                     if (t1 <= 0.0f) continue;
                     if (t1 < best_t) { best_t = t1; best_node = -2 - l; best_front = 1; break; }
                 }
-                io.put_closest(ray_i, best_t, best_node, best_face, best_front, best_u, best_v);
+                io.put_closest(tag, best_t, best_node, best_face, best_front, best_u, best_v);
                 active = false;
             }
         }
@@ -206,7 +253,31 @@ template <bool COUNT, int LEVELS, class IO> struct RayWalker {
             }
             if (cur != kNoNode) {
                 if (cur & kLeafBit) { at_leaf = true; leaf_data = cur; leaf_i = 0; cur = kNoNode; }
-                else {
+                else if (kWide) {
+                    const GF4 rec = (GF4)S.bvh4_pool + (size_t)cur * 8;
+                    const f4 a0 = rec[0], a1 = rec[1], b0 = rec[2], b1 = rec[3], c0 = rec[4], c1 = rec[5], e0 = rec[6], e1 = rec[7];
+                    float d0, d1, d2, d3;
+                    const bool h0 = bvh_box(exact, lr.p, inv, t_limit, a0, a1, d0) && d0 < t_limit;
+                    const bool h1 = bvh_box(exact, lr.p, inv, t_limit, b0, b1, d1) && d1 < t_limit;
+                    const bool h2 = bvh_box(exact, lr.p, inv, t_limit, c0, c1, d2) && d2 < t_limit;
+                    const bool h3 = bvh_box(exact, lr.p, inv, t_limit, e0, e1, d3) && d3 < t_limit;
+                    uint32_t k0 = __float_as_uint(a1.z), k1 = __float_as_uint(b1.z), k2 = __float_as_uint(c1.z), k3 = __float_as_uint(e1.z);
+                    // boxes the ray does not enter sort to the end
+                    d0 = h0 && k0 != kNoNode ? d0 : INFINITY; d1 = h1 && k1 != kNoNode ? d1 : INFINITY;
+                    d2 = h2 && k2 != kNoNode ? d2 : INFINITY; d3 = h3 && k3 != kNoNode ? d3 : INFINITY;
+                    const auto order = [](float &da, uint32_t &ka, float &db, uint32_t &kb) {
+                        const bool sw = db < da;
+                        const float td = sw ? db : da; const uint32_t tk = sw ? kb : ka;
+                        db = sw ? da : db; kb = sw ? ka : kb;
+                        da = td; ka = tk;
+                    };
+                    order(d0, k0, d1, k1); order(d2, k2, d3, k3); order(d0, k0, d2, k2); order(d1, k1, d3, k3); order(d1, k1, d2, k2);
+                    // farthest first onto the stack, the nearest is visited next
+                    if (d3 < INFINITY) { st.push(sp, k3, d3); ++sp; }
+                    if (d2 < INFINITY) { st.push(sp, k2, d2); ++sp; }
+                    if (d1 < INFINITY) { st.push(sp, k1, d1); ++sp; }
+                    cur = d0 < INFINITY ? k0 : kNoNode;
+                } else {
                     const uint32_t c1 = cur & 0x7FFFFFFFu;
                     const f4 a0 = bvh[c1 * 2], a1 = bvh[c1 * 2 + 1], b0 = bvh[c1 * 2 + 2], b1 = bvh[c1 * 2 + 3];
                     float d1, d2;
@@ -271,9 +342,16 @@ template <bool COUNT, int LEVELS, class IO> struct RayWalker {
     }
 };
 
+// The list is handed out in chunks of ray_chunk entries, one atomic per chunk and wave.  With parts > 1 the list is cut
+// into that many parts with a queue word each (128 bytes apart): part p holds the p-th slice of the entries before
+// n_split and the p-th slice of the entries after it (for the path tracer: extension rays and shadow rays of the same
+// region of the image).  Workgroup b starts on part b % parts - workgroups are dealt to the eight XCDs round-robin, so
+// with eight parts each XCD's L2 sees the rays, and with them the BVH nodes, of one eighth of the list - and goes on to
+// the next part when its own is used up.
 template <bool COUNT, int LEVELS, class IO>
 __global__ __launch_bounds__(kBlock, RT_RAYS_MIN_WAVES) void k_rays(DScene S, IO io, uint32_t n_rays, DCounters *ctr,
-                                                                  unsigned long long *queue, uint32_t ray_chunk)
+                                                                  unsigned long long *queue, uint32_t ray_chunk,
+                                                                  uint32_t n_split, uint32_t parts)
 {
     extern __shared__ uint32_t lds[];
     const LaneStack st = lane_stack(lds, S);
@@ -281,11 +359,14 @@ __global__ __launch_bounds__(kBlock, RT_RAYS_MIN_WAVES) void k_rays(DScene S, IO
     PathTally pt;
     Tally<COUNT> tl;
     RayWalker<COUNT, LEVELS, IO> w;
-    w.lv.init(w.wray);
 
-    // wave-uniform window of the ray list
+    // wave-uniform window of the ray list: entries [chunk_next, chunk_end) of part q (part-local numbering)
     uint32_t chunk_next = 0, chunk_end = 0;
     bool exhausted = false;
+    uint32_t q = blockIdx.x % parts, tried = 0;
+    const uint32_t n_first = n_split < n_rays ? n_split : n_rays, n_second = n_rays - n_first;
+    // slice p of a range of n entries: [p * n / parts, (p + 1) * n / parts)
+    auto slice = [parts](uint32_t n, uint32_t p) { return (uint32_t)((uint64_t)n * p / parts); };
 
     // A lane is idle, stepping through the scene nodes, walking a BVH, or parked at a leaf.  The wave
     // runs each kind of step for all lanes that wait for it at once, and lets lanes wait until enough
@@ -297,23 +378,32 @@ __global__ __launch_bounds__(kBlock, RT_RAYS_MIN_WAVES) void k_rays(DScene S, IO
         const uint64_t idle = __ballot(!w.active);
         pt.tock(12);
         if (idle != 0 && !exhausted && ((uint32_t)__popcll(idle) >= (uint32_t)RT_RAYS_REFILL_MIN_LANES || !__any(w.in_bvh))) {
-            if (chunk_next >= chunk_end) {
+            while (chunk_next >= chunk_end && !exhausted) {
                 unsigned long long b = 0;
-                if (lane == 0) b = atomicAdd(queue, (unsigned long long)ray_chunk);
+                if (lane == 0) b = atomicAdd(&queue[q * kQueueStride], (unsigned long long)ray_chunk);
                 b = __shfl(b, 0, 64);
-                chunk_next = b < n_rays ? (uint32_t)b : n_rays;
-                chunk_end = b + ray_chunk < n_rays ? (uint32_t)(b + ray_chunk) : n_rays;
-                if (chunk_next >= chunk_end) exhausted = true;
+                const uint32_t len = (slice(n_first, q + 1) - slice(n_first, q)) + (slice(n_second, q + 1) - slice(n_second, q));
+                if (b < len) { chunk_next = (uint32_t)b; chunk_end = b + ray_chunk < len ? (uint32_t)(b + ray_chunk) : len; }
+                else if (++tried >= parts) exhausted = true;
+                else q = (q + 1) % parts;
             }
             const uint32_t avail = chunk_end - chunk_next;
             const uint32_t want = (uint32_t)__popcll(idle);
             const uint32_t take = avail < want ? avail : want;
             const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-            if (!w.active && rank < take) {
-                const uint32_t e = chunk_next + rank;
-                float4 o, d; bool shadow; float tmax;
-                if (io.fetch(e, o, d, shadow, tmax)) w.start(e, o, d, shadow, tmax, pt); // a list may have holes
-            }
+            const bool taking = !w.active && rank < take;
+            typename IO::Pending pend; // what the lane's finished shadow ray still has to hand over: its loads go out first
+            const bool owes = IO::kDeferShadow && !w.active && w.unoccluded;
+            if (owes) io.begin_put_shadow(w.tag, pend);
+            if (taking) {
+                const uint32_t i = chunk_next + rank, first_len = slice(n_first, q + 1) - slice(n_first, q);
+                const uint32_t e = i < first_len ? slice(n_first, q) + i : n_first + slice(n_second, q) + (i - first_len);
+                float4 o, d; bool shadow; float tmax; uint32_t tg;
+                const uint32_t old = w.tag;
+                const bool got = io.fetch(e, o, d, shadow, tmax, tg); // a list may have holes
+                if (owes) { io.end_put_shadow(old, pend); w.unoccluded = false; }
+                if (got) w.start(tg, o, d, shadow, tmax, pt);
+            } else if (owes) { io.end_put_shadow(w.tag, pend); w.unoccluded = false; }
             chunk_next += take;
             pt.ran(0, idle);
         }
@@ -323,6 +413,7 @@ __global__ __launch_bounds__(kBlock, RT_RAYS_MIN_WAVES) void k_rays(DScene S, IO
         }
         w.phases(S, io, st, pt, tl);
     }
+    if (IO::kDeferShadow && w.unoccluded) { typename IO::Pending pend; io.begin_put_shadow(w.tag, pend); io.end_put_shadow(w.tag, pend); }
     flush_counters<COUNT>(ctr, pt, tl, 0);
 }
 

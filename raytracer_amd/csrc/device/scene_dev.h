@@ -25,15 +25,32 @@ struct DNode {
     int32_t pad[2];
 }; // 176 bytes
 
-// One triangle mesh.
-//   bvh  : 32-byte nodes, two float4 each: (min.x, max.x, min.y, max.y) (min.z, max.z, data, 0);
+// Scene-graph node as the ray-list kernel reads it: one 128-byte record, fetched with a wave-uniform index through
+// the scalar cache.  A mesh node carries the root of its BVH (box and data word), so a ray enters the walk without
+// another dependent fetch.
+struct TNode {
+    float itm[12];
+    uint32_t meta;    // prim | depth << 8 | has_children << 16
+    uint32_t root;    // mesh: data word of the BVH root (first child / leaf range, pool numbering)
+    uint32_t root4;   // mesh: the same for the four-wide form of the BVH (record index in bvh4_pool / leaf range)
+    float box[6];     // mesh: root box as the slab test wants it: min.x, max.x, min.y, max.y, min.z, max.z
+    float wbox[6];    // world-space box around the node's own object, padded: min xyz, max xyz (-/+FLT_MAX: unknown)
+    uint32_t pad[5];
+};
+static_assert(sizeof(TNode) == 128, "one TNode per 128-byte line");
+
+// One triangle mesh.  The BVH nodes and triangle records of all meshes of a scene live in two pools (one
+// allocation each); node ids and triangle offsets inside the BVH data words are pool indices.
+//   bvh  : the node pool.  32-byte nodes, two float4 each: (min.x, max.x, min.y, max.y) (min.z, max.z, data, 0);
 //          the two children of a node are adjacent, the pair starts on a 64-byte line
-//   tris : 48-byte records in BVH-leaf order (indexed by element slot, not face id):
+//   tris : the triangle pool.  48-byte records in BVH-leaf order (indexed by element slot, not face id):
 //          (v0.xyz, v1.x) (v1.yz, v2.xy) (v2.z, face id, 0, 0) - the three position
 //          reads and the two index reads of the reference collapse into one dependent fetch
 struct DMesh {
     const float4 *bvh;
     const float4 *tris;
+    uint32_t root;      // pool id of this mesh's root node
+    uint32_t pad_;
     const uint32_t *fn; // normal indices per face
     const uint32_t *ft; // tex-coord indices per face
     const float *vn;
@@ -53,6 +70,13 @@ struct DTexture {
 
 struct DScene {
     const DNode *nodes;
+    const TNode *tnodes;       // the same nodes, compact (ray-list kernel)
+    const float4 *bvh_pool;    // BVH nodes of all meshes
+    const float4 *tri_pool;    // triangle records of all meshes
+    // Four-wide form of the same BVHs: a record is one 128-byte line holding up to four nodes in the 32-byte layout
+    // of bvh_pool - the grandchildren of a node of the binary tree (a child that is a leaf stands for itself).  The
+    // data word of an inner node is the index of its own record; unused places hold boxes no ray enters and kNoNode.
+    const float4 *bvh4_pool;
     const DMesh *meshes;
     const rt_material *materials;
     const rt_light *lights;

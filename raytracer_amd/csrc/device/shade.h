@@ -237,11 +237,9 @@ RT_DEV void path_begin(PathState &ps, Ray ray)
 // One iteration of the bounce loop of tracePath (src/main.cpp:170-265).  Returns
 // false when the path has ended; ps.result then holds its radiance.  first_z /
 // first_id receive depth and node id of the camera ray's hit when non-null.
-// With RESUME the closest-hit query may come back unfinished (see WalkState): the step then changes nothing
-// else and returns true, and the next call for this lane takes the query up again.
-template <bool COUNT, int LEVELS, bool TEXBG = true, bool RESUME = false>
+template <bool COUNT, int LEVELS, bool TEXBG = true>
 RT_DEV bool path_step(const DScene &S, const DFrame &F, PathState &ps, LaneStack st, PathTally &pt,
-                      Tally<COUNT> &tl, float *first_z, int *first_id, WalkState *ws = nullptr)
+                      Tally<COUNT> &tl, float *first_z, int *first_id)
 {
     if (ps.bounce >= F.max_bounces) return false;
     tl.step(6);
@@ -251,13 +249,8 @@ RT_DEV bool path_step(const DScene &S, const DFrame &F, PathState &ps, LaneStack
     Hit h;
     bool hit;
     pt.tick();
-    if constexpr (RESUME) {
-        if (ws->node < 0) ++pt.closest;
-        if (trace_closest_resumable<COUNT, LEVELS>(S, ray, st, h, hit, *ws, tl)) { pt.tock(0); return true; }
-    } else {
-        ++pt.closest;
-        hit = trace_closest<COUNT, LEVELS>(S, ray, st, h, tl);
-    }
+    ++pt.closest;
+    hit = trace_closest<COUNT, LEVELS>(S, ray, st, h, tl);
     pt.tock(0);
     if (ps.bounce == 0 && first_z) { *first_z = h.z; *first_id = hit ? h.node : -1; }
     if (!hit) {

@@ -268,33 +268,8 @@ RT_DEV bool mesh_traverse(const DMesh &M, Ray r, float t_limit, bool any_hit, La
     const bool exact = needs_exact_slabs(r.p, inv);
     const GF4 bvh = (GF4)M.bvh, tris = (GF4)M.tris;
     int sp = 0;
-#ifdef RT_NEAR_IN_REGISTER
-    // the node to visit next stays in a register: of two children that are hit only the farther one goes to the
-    // stack (the reference pushes both and pops the nearer one at once; its entry distance was just tested
-    // against the closest hit so far, so the pop-time test cannot fail for it)
-    constexpr uint32_t kNone = 0x7FFFFFFFu; // not a data word: an inner node's first child index is far smaller
-    uint32_t cur;
     {
-        const f4 r0 = bvh[2], r1 = bvh[3];
-        float dist;
-        tl.boxes(1);
-        if (!bvh_box(exact, r.p, inv, t_limit, r0, r1, dist)) return false;
-        cur = __float_as_uint(r1.z);
-    }
-    bool hit = false;
-    for (;;) {
-        uint32_t data;
-        if (cur == kNone) {
-            if (sp == 0) break;
-            --sp;
-            float nodeT;
-            st.pop(sp, data, nodeT);
-            if (t_limit < nodeT) { tl.step(any_hit ? 5 : 2); continue; } // entered farther than the best hit so far
-        } else data = cur;
-        cur = kNone;
-#else
-    {
-        const f4 r0 = bvh[2], r1 = bvh[3];
+        const f4 r0 = bvh[M.root * 2], r1 = bvh[M.root * 2 + 1];
         float dist;
         tl.boxes(1);
         if (!bvh_box(exact, r.p, inv, t_limit, r0, r1, dist)) return false;
@@ -307,7 +282,6 @@ RT_DEV bool mesh_traverse(const DMesh &M, Ray r, float t_limit, bool any_hit, La
         uint32_t data; float nodeT;
         st.pop(sp, data, nodeT);
         if (t_limit < nodeT) { tl.step(any_hit ? 5 : 2); continue; } // entered farther than the best hit so far
-#endif
         if (data & kLeafBit) {
             const uint32_t off = data & 0x0FFFFFFFu;
             const uint32_t cnt = ((data >> 28) & 7u) + 1;
@@ -344,11 +318,6 @@ RT_DEV bool mesh_traverse(const DMesh &M, Ray r, float t_limit, bool any_hit, La
         bool h2 = bvh_box(exact, r.p, inv, t_limit, b0, b1, d2);
         h2 = h2 && d2 < t_limit;
         const uint32_t k1 = __float_as_uint(a1.z), k2 = __float_as_uint(b1.z);
-#ifdef RT_NEAR_IN_REGISTER
-        const bool firstNear = d1 < d2; // on a tie the second child is visited first
-        if (h1 && h2) { st.push(sp, firstNear ? k2 : k1, firstNear ? d2 : d1); ++sp; }
-        cur = h1 ? ((h2 && !firstNear) ? k2 : k1) : (h2 ? k2 : kNone);
-#else
         if (h1 && h2) {
             // nearer child on top of the stack; on a tie the second child is visited first
             const bool firstNear = d1 < d2;
@@ -357,7 +326,6 @@ RT_DEV bool mesh_traverse(const DMesh &M, Ray r, float t_limit, bool any_hit, La
         } else if (h1 || h2) {
             st.push(sp, h1 ? k1 : k2, h1 ? d1 : d2); ++sp;
         }
-#endif
     }
     tOut = t_limit;
     return hit;
@@ -375,106 +343,6 @@ RT_DEV bool mesh_shadow(const DMesh &M, Ray r, float t_max, LaneStack st, Tally<
 {
     float t, u, v, det; uint32_t face;
     return mesh_traverse<COUNT>(M, r, t_max, true, st, t, face, u, v, det, tl);
-}
-
-// ---- closest-hit walks that can be put down and taken up again ----
-// Walk lengths are long-tailed: most rays need a dozen node visits, a few need hundreds, and a wave that waits
-// for its longest ray runs most of its trips with a handful of lanes.  A resumable walk ends, for the whole
-// wave, once few lanes are still walking while others have finished; the unfinished lanes keep their walk
-// (the stack stays where it is, the rest is in WalkState) and take it up again in the wave's next closest-hit
-// query, side by side with the fresh rays of the lanes that went on.  A lane computes exactly what it would
-// have computed in one go: only the moment changes.
-// Measured on the 1M-triangle frame (RT_RESUMABLE_WALKS=1): the node-visit trips of closest-hit walks fall
-// from 221 M to 103 M per frame (15 -> 32 lanes per trip), but leaf trips stay (157 M at 3.5 lanes: every trip
-// still has some lane at a leaf), the shadow walks and the shading run in more, emptier rounds (4.9 M instead
-// of 4.0 M), and the frame is 13 % slower (2.29 against 2.64 Grays/s; thresholds 8/16/24/32: 2.39/2.29/2.15/1.95).
-// Kept as a switch: the walk is the building block for a kernel in which leaves are batched as well.
-#ifndef RT_SUSPEND_BELOW
-#define RT_SUSPEND_BELOW 16 // lanes still walking below which a wave stops waiting for them
-#endif
-struct WalkState {
-    int node = -1;             // scene node whose mesh the walk is in, -1: no walk in progress
-    int sp = 0;                // stack entries
-    float t_limit = FLT_MAX;   // closest hit of this mesh so far
-    bool hit = false;
-    uint32_t face = 0; float u = 0, v = 0, det = 0;
-    // closest hit over the scene nodes before `node`
-    float best_z = FLT_MAX; int best_node = -1, best_front = 1; uint32_t best_face = 0; float best_u = 0, best_v = 0;
-};
-
-// TriObj::IntersectRay (src/TriObj.cpp:12-136) as mesh_traverse() walks it, for a wave whose lanes either start
-// the walk (resume = false) or continue one (w holds it).  Returns true while the lane's walk is unfinished.
-template <bool COUNT>
-RT_DEV bool mesh_closest_resumable(const DMesh &M, Ray r, LaneStack st, bool resume, WalkState &w, Tally<COUNT> &tl)
-{
-    const float epsilon = 1e-6f;
-    const V3 inv = mk(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
-    const bool exact = needs_exact_slabs(r.p, inv);
-    const GF4 bvh = (GF4)M.bvh, tris = (GF4)M.tris;
-    if (!resume) {
-        w.sp = 0; w.t_limit = FLT_MAX; w.hit = false;
-        const f4 r0 = bvh[2], r1 = bvh[3];
-        float dist;
-        tl.boxes(1);
-        if (bvh_box(exact, r.p, inv, w.t_limit, r0, r1, dist)) { st.push(0, __float_as_uint(r1.z), dist); w.sp = 1; }
-    }
-    int sp = w.sp;
-    float t_limit = w.t_limit;
-    const uint32_t n_entered = (uint32_t)__popcll(__ballot(true));
-    for (;;) {
-        const uint32_t n_walk = (uint32_t)__popcll(__ballot(sp > 0));
-        if (n_walk == 0) break;
-        // stop waiting once few lanes walk and at least as many again have something else to do
-        if (n_walk < (uint32_t)RT_SUSPEND_BELOW && n_walk * 2 < n_entered) break;
-        if (sp > 0) {
-            --sp;
-            uint32_t data; float nodeT;
-            st.pop(sp, data, nodeT);
-            if (t_limit < nodeT) { tl.step(2); continue; } // entered farther than the best hit so far
-            if (data & kLeafBit) {
-                const uint32_t off = data & 0x0FFFFFFFu;
-                const uint32_t cnt = ((data >> 28) & 7u) + 1;
-                for (uint32_t i = 0; i < cnt; i += 2) { // two triangles per trip: their six loads are in flight together
-                    tl.step(1);
-                    const GF4 ra = &tris[(off + i) * 3];
-                    const bool two = i + 1 < cnt;
-                    const GF4 rb = two ? ra + 3 : ra;
-                    const f4 a0 = ra[0], a1 = ra[1], a2 = ra[2], b0 = rb[0], b1 = rb[1], b2 = rb[2];
-                    float t, u, v, det; uint32_t face;
-                    tl.tris(1);
-                    if (tri_test(a0, a1, a2, r, t, u, v, det, face) && !(t <= epsilon || t > t_limit)) {
-                        w.hit = true; w.det = det; w.u = u; w.v = v; w.face = face; t_limit = t;
-                    }
-                    tl.tris(two ? 1 : 0);
-                    if (two && tri_test(b0, b1, b2, r, t, u, v, det, face) && !(t <= epsilon || t > t_limit)) {
-                        w.hit = true; w.det = det; w.u = u; w.v = v; w.face = face; t_limit = t;
-                    }
-                }
-                continue;
-            }
-            const uint32_t c1 = data & 0x7FFFFFFFu;
-            const f4 a0 = bvh[c1 * 2], a1 = bvh[c1 * 2 + 1], b0 = bvh[c1 * 2 + 2], b1 = bvh[c1 * 2 + 3];
-            float d1, d2;
-            tl.boxes(2);
-            tl.step(0);
-            bool h1 = bvh_box(exact, r.p, inv, t_limit, a0, a1, d1);
-            h1 = h1 && d1 < t_limit;
-            bool h2 = bvh_box(exact, r.p, inv, t_limit, b0, b1, d2);
-            h2 = h2 && d2 < t_limit;
-            const uint32_t k1 = __float_as_uint(a1.z), k2 = __float_as_uint(b1.z);
-            if (h1 && h2) {
-                // nearer child on top of the stack; on a tie the second child is visited first
-                const bool firstNear = d1 < d2;
-                st.push(sp, firstNear ? k2 : k1, firstNear ? d2 : d1); ++sp;
-                st.push(sp, firstNear ? k1 : k2, firstNear ? d1 : d2); ++sp;
-            } else if (h1 || h2) {
-                st.push(sp, h1 ? k1 : k2, h1 ? d1 : d2); ++sp;
-            }
-        }
-    }
-    w.sp = sp;
-    w.t_limit = t_limit;
-    return sp > 0;
 }
 
 // per-level local rays, selected by the wave-uniform node depth.  Value selects
@@ -515,17 +383,20 @@ template <int LEVELS> struct RayLevels {
     RT_DEV void init(Ray v) { r0 = r1 = r2 = r3 = r4 = v; }
 };
 
-// Does the ray reach the node's world-space box before t_max?  Used only to skip work (CULL): the boxes are padded,
-// so approximate reciprocals are good enough, and a NaN anywhere says "reaches".
+// Does the ray reach the node's world-space box before t_max?  Used only to skip work: the boxes are padded, so
+// approximate reciprocals are good enough.  Whatever cannot be decided says "reaches": a NaN among the six slab
+// distances (0 * inf: a direction component of exactly zero with the origin exactly on a box plane) is looked for
+// explicitly, because the min / max instructions would drop it.
 RT_DEV V3 cull_inverse(V3 d) { return mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z)); }
 RT_DEV bool reaches_box(const float *b, V3 p, V3 inv, float t_max)
 {
     const float x1 = (b[0] - p.x) * inv.x, x2 = (b[3] - p.x) * inv.x;
     const float y1 = (b[1] - p.y) * inv.y, y2 = (b[4] - p.y) * inv.y;
     const float z1 = (b[2] - p.z) * inv.z, z2 = (b[5] - p.z) * inv.z;
-    const float tNear = fmaxf(fmaxf(fmaxf(fminf(x1, x2), fminf(y1, y2)), fminf(z1, z2)), 0.0f);
-    const float tFar = fminf(fminf(fminf(fmaxf(x1, x2), fmaxf(y1, y2)), fmaxf(z1, z2)), t_max);
-    return !(tNear > tFar);
+    const bool undecided = __builtin_isunordered(x1, x2) || __builtin_isunordered(y1, y2) || __builtin_isunordered(z1, z2);
+    const float tNear = vmax(vmax3(vmin(x1, x2), vmin(y1, y2), vmin(z1, z2)), 0.0f);
+    const float tFar = vmin(vmin3(vmax(x1, x2), vmax(y1, y2), vmax(z1, z2)), t_max);
+    return undecided || !(tNear > tFar);
 }
 
 // shootRay + shootRayAtLights (src/main.cpp:16-70,115-120).  The winner is the
@@ -590,68 +461,6 @@ RT_DEV bool trace_closest(const DScene &S, Ray ray, LaneStack st, Hit &h, Tally<
         if (t1 < h.z) { h.z = t1; h.node = -2 - l; h.front = 1; hit = true; break; }
     }
     return hit;
-}
-
-// trace_closest() with resumable mesh walks.  Returns true while the query is unfinished (w.node says where it
-// stands); when it returns false, h holds the answer as trace_closest() would have left it and `hit` says
-// whether anything was hit.
-template <bool COUNT, int LEVELS>
-RT_DEV bool trace_closest_resumable(const DScene &S, Ray ray, LaneStack st, Hit &h, bool &hit, WalkState &w, Tally<COUNT> &tl)
-{
-    const int resume_at = w.node; // -1: a new query
-    h.z = w.best_z; h.node = w.best_node; h.front = w.best_front; h.face = w.best_face; h.u = w.best_u; h.v = w.best_v;
-    if (resume_at < 0) { h.z = FLT_MAX; h.node = -1; h.front = 1; h.face = 0; h.u = 0; h.v = 0; }
-    bool suspended = false;
-    RayLevels<LEVELS> lv;
-    lv.init(ray);
-    const int n = S.n_nodes;
-    for (int i = 0; i < n; ++i) {
-        const DNode &nd = S.nodes[i];
-        const int d = nd.depth;
-        const Ray parent = (d == 0) ? ray : lv.get(d - 1);
-        const Ray lr = to_node(nd, parent);
-        if (nd.has_children) lv.set(d, lr);
-        const int prim = nd.prim;
-        if (prim == RT_PRIM_NONE) continue;
-        if (suspended || i < resume_at) continue; // put down at an earlier node in this call / done before the walk was put down
-        float t = 0; int front = 1; bool ok = false;
-        uint32_t face = 0; float u = 0, v = 0;
-        if (prim == RT_PRIM_SPHERE) ok = sphere_t(lr, t, front);
-        else if (prim == RT_PRIM_PLANE) ok = plane_t(lr, t, front);
-        else {
-            if (mesh_closest_resumable<COUNT>(S.meshes[nd.mesh], lr, st, i == resume_at, w, tl)) {
-                suspended = true;
-                w.node = i;
-                w.best_z = h.z; w.best_node = h.node; w.best_front = h.front; w.best_face = h.face; w.best_u = h.u; w.best_v = h.v;
-                continue;
-            }
-            ok = w.hit; t = w.t_limit; face = w.face; u = w.u; v = w.v;
-            front = w.det > 0.0f;
-        }
-        if (ok && t < h.z) { h.z = t; h.node = i; h.front = front; h.face = face; h.u = u; h.v = v; }
-    }
-    if (suspended) return true;
-    w.node = -1;
-    hit = h.node >= 0;
-    // spherical lights, front side only (src/lights.h:129-156 via the default hitSide of scene.h:273)
-    for (int l = 0; l < S.n_lights; ++l) {
-        const rt_light &L = S.lights[l];
-        if (L.type != RT_LIGHT_POINT) continue;
-        Ray r;
-        r.p = (ray.p - ld3(L.position)) / L.size;
-        r.d = ray.d / L.size;
-        const float a = dot(r.d, r.d);
-        const float b = 2 * dot(r.d, r.p);
-        const float c = dot(r.p, r.p) - 1.0f;
-        const float disc = b * b - 4 * a * c;
-        if (disc < 0.0f) continue;
-        const float s = fsqrt(disc);
-        const float inv2a = 1.0f / (2.0f * a);
-        const float t1 = (-b - s) * inv2a;
-        if (t1 <= 0.0f) continue;
-        if (t1 < h.z) { h.z = t1; h.node = -2 - l; h.front = 1; hit = true; break; }
-    }
-    return false;
 }
 
 // Hit attributes of the winning object, then its way back up the hierarchy

@@ -42,29 +42,39 @@ struct WfState {
 // ray list of k_rays: entries [0, n_ext) are the extension rays of the slots the queue names (slot e itself without a
 // queue: the camera rays), entries [n_ext, n_ext + n_shadow) the shadow rays of the slots the shadow queue names
 struct WfIO {
+    static constexpr bool kDeferShadow = true;
+    struct Pending { float4 c, a; };
     WfState P;
     const uint32_t *queue, *sh_queue;
     uint32_t n_ext;
-    RT_DEV bool fetch(uint32_t e, float4 &o, float4 &d, bool &any_hit, float &t_max) const
+    RT_DEV void refetch(uint32_t slot, bool any_hit, float4 &o, float4 &d) const
+    {
+        if (any_hit) { o = P.sh_o[slot]; d = P.sh_d[slot]; }
+        else { o = P.ray_o[slot]; d = P.ray_d[slot]; }
+    }
+    // the lane keeps the slot: every later access goes straight to the path's arrays
+    RT_DEV bool fetch(uint32_t e, float4 &o, float4 &d, bool &any_hit, float &t_max, uint32_t &slot) const
     {
         any_hit = e >= n_ext;
-        if (any_hit) { const uint32_t slot = sh_queue[e - n_ext]; o = P.sh_o[slot]; d = P.sh_d[slot]; t_max = o.w; }
-        else {
-            const uint32_t slot = queue ? queue[e] : e;
-            o = P.ray_o[slot]; d = P.ray_d[slot]; t_max = 0.0f;
-        }
+        slot = any_hit ? sh_queue[e - n_ext] : (queue ? queue[e] : e);
+        refetch(slot, any_hit, o, d);
+        t_max = any_hit ? o.w : 0.0f;
         return true;
     }
-    RT_DEV void put_closest(uint32_t e, float t, int node, uint32_t face, int front, float u, float v) const
+    // an unoccluded shadow ray adds the contribution it gates to its path's accumulator
+    RT_DEV void begin_put_shadow(uint32_t slot, Pending &p) const { p.c = P.sh_c[slot]; p.a = P.acc[slot]; }
+    RT_DEV void end_put_shadow(uint32_t slot, const Pending &p) const
     {
-        const uint32_t slot = queue ? queue[e] : e;
+        P.acc[slot] = make_float4(p.a.x + p.c.x, p.a.y + p.c.y, p.a.z + p.c.z, p.a.w);
+    }
+    RT_DEV void put_closest(uint32_t slot, float t, int node, uint32_t face, int front, float u, float v) const
+    {
         P.hit[slot] = make_float4(t, __uint_as_float((uint32_t)node), __uint_as_float(face | ((uint32_t)front << 31)), u);
         P.hit_v[slot] = v;
     }
-    RT_DEV void put_shadow(uint32_t e, bool occluded) const
+    RT_DEV void put_shadow(uint32_t slot, bool occluded) const
     {
         if (occluded) return;
-        const uint32_t slot = sh_queue[e - n_ext];
         const float4 c = P.sh_c[slot];
         float4 a = P.acc[slot];
         a.x = a.x + c.x; a.y = a.y + c.y; a.z = a.z + c.z;

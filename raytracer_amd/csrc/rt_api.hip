@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <memory>
 #include <string>
 #include <vector>
@@ -63,7 +64,7 @@ struct rt_ctx {
     // scene
     bool have_scene = false, have_meshes = false;
     DScene scene{};
-    DeviceBuf d_nodes, d_meshes, d_materials, d_lights, d_textures;
+    DeviceBuf d_nodes, d_tnodes, d_meshes, d_materials, d_lights, d_textures;
     std::vector<std::unique_ptr<DeviceBuf>> mesh_bufs;
     std::vector<int> host_node_material; // for validation
     // camera
@@ -78,6 +79,7 @@ struct rt_ctx {
     DeviceBuf d_wf_state, d_wf_queue[2], d_wf_sh_queue, d_wf_counts;
     static constexpr int kMaxRayLaunches = 96;
     hipEvent_t ray_ev[2 * kMaxRayLaunches] = {};
+    int ray_parts = 8; // RT_RAY_PARTS: parts the ray lists of the large launches are cut into, one per XCD (1..8)
     int pipeline = -1; // RT_PIPELINE: 0 = lock-step path kernel (k_paths), 1 = wavefront; -1: chosen per scene (wavefront when it has meshes)
     size_t ovf_threads = 0;
     int lds_levels_max = 13;
@@ -276,7 +278,8 @@ static int render_wavefront(rt_ctx *ctx, const DFrame &F, const int32_t *act, ui
             // rays a wave reserves at a time: few atomics on the queue word in the large launches, enough chunks for every wave in the small ones
             const uint64_t per_wave = n_rays / ((uint64_t)grid.x * (kBlock / 64)) / 8;
             uint32_t a_chunk = per_wave >= 1024 ? 1024u : per_wave >= 512 ? 512u : per_wave >= 256 ? 256u : per_wave >= 128 ? 128u : 64u;
-            void *targs[] = {&a_scene, &a_io, &a_n, &a_ctr, &a_queue, &a_chunk};
+            uint32_t a_split = n_ext, a_parts = n_rays >= (1u << 20) ? (uint32_t)ctx->ray_parts : 1u;
+            void *targs[] = {&a_scene, &a_io, &a_n, &a_ctr, &a_queue, &a_chunk, &a_split, &a_parts};
             HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue.p, 0, kQueueBytes, s));
             const bool timed = launch < rt_ctx::kMaxRayLaunches;
             if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ray_ev[2 * launch], s));
@@ -363,6 +366,7 @@ int rt_init(int device, rt_ctx **out)
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
     ctx->n_cu = prop.multiProcessorCount;
+    if (const char *e9 = getenv("RT_RAY_PARTS")) ctx->ray_parts = std::max(1, std::min(8, atoi(e9)));
     if (const char *e3 = getenv("RT_PIPELINE")) ctx->pipeline = strcmp(e3, "wave") == 0 ? 1 : strcmp(e3, "mega") == 0 ? 0 : -1;
     for (hipEvent_t &ev : ctx->ray_ev)
         if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
@@ -438,7 +442,7 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc)
     if (sc->n_lights < 1 || !sc->lights || sc->lights[0].type != RT_LIGHT_POINT || !(sc->lights[0].size > 0.0f))
         return ctx->fail(RT_ERR_UNSUPPORTED, "the path integrator needs lights[0] to be a point light with size > 0 (src/main.cpp:165)");
 
-    // ---- meshes ----
+    // ---- meshes: BVH nodes and triangle records of all meshes go into two pools; ids in the data words become pool ids ----
     std::vector<DMesh> dmeshes(sc->n_meshes);
     std::vector<std::unique_ptr<DeviceBuf>> bufs;
     auto upload = [&](const void *src, size_t bytes, const void **dst) -> hipError_t {
@@ -450,16 +454,28 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc)
         bufs.push_back(std::move(b));
         return e;
     };
+    std::vector<uint32_t> node_base(sc->n_meshes), tri_base(sc->n_meshes);
+    size_t pool_nodes = 2, pool_tris = 0; // pool node 0/1 unused: pairs of children start at even ids
     for (uint32_t mi = 0; mi < sc->n_meshes; ++mi) {
         const rt_mesh &m = sc->meshes[mi];
         if (!m.v || !m.vn || !m.vt || !m.f || !m.fn || !m.ft || !m.bvh_nodes || !m.bvh_elements || m.nf == 0 || m.n_bvh_nodes < 2)
             return ctx->fail(RT_ERR_INVALID, "mesh %u: missing arrays (positions, normals, tex coords, faces and BVH are all required)", mi);
+        node_base[mi] = (uint32_t)pool_nodes; tri_base[mi] = (uint32_t)pool_tris;
+        pool_nodes += ((size_t)m.n_bvh_nodes + 1) / 2 * 2;
+        pool_tris += m.nf;
+        if (pool_nodes >= ((size_t)1 << 31) || pool_tris >= ((size_t)1 << 28)) return ctx->fail(RT_ERR_UNSUPPORTED, "scene has more than 2^28 triangles");
+    }
+    std::vector<float4> bvh(pool_nodes * 2, make_float4(0, 0, 0, 0));
+    std::vector<float4> tris(pool_tris * 3);
+    std::vector<rt_bvh_node> roots(sc->n_meshes);
+    std::vector<float4> bvh4; // records of eight float4
+    std::vector<uint32_t> root4(sc->n_meshes, 0);
+    for (uint32_t mi = 0; mi < sc->n_meshes; ++mi) {
+        const rt_mesh &m = sc->meshes[mi];
         for (size_t k = 0; k < (size_t)m.nf * 3; ++k)
             if (m.f[k] >= m.nv || m.fn[k] >= m.nvn || m.ft[k] >= m.nvt) return ctx->fail(RT_ERR_INVALID, "mesh %u: face index out of range", mi);
         // BVH: walk it once - checks indices, finds the depth, proves it is a tree
-        std::vector<float4> bvh((size_t)m.n_bvh_nodes * 2);
-        std::vector<float4> tris((size_t)m.nf * 3);
-        std::vector<uint8_t> seen(m.nf, 0);
+        const uint32_t nb = node_base[mi], tb = tri_base[mi];
         uint32_t depth = 0;
         size_t visited = 0;
         std::vector<std::pair<uint32_t, uint32_t>> stack{{1u, 0u}};
@@ -469,37 +485,97 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc)
             if (id == 0 || id >= m.n_bvh_nodes || ++visited > m.n_bvh_nodes) return ctx->fail(RT_ERR_INVALID, "mesh %u: BVH node index out of range or cyclic", mi);
             depth = std::max(depth, lvl);
             const rt_bvh_node &b = m.bvh_nodes[id];
-            // bounds = min.xyz, max.xyz; stored interleaved per axis (see bvh_box_fast)
-            bvh[id * 2] = make_float4(b.bounds[0], b.bounds[3], b.bounds[1], b.bounds[4]);
-            bvh[id * 2 + 1] = make_float4(b.bounds[2], b.bounds[5], __builtin_bit_cast(float, b.data), 0.0f);
+            uint32_t data;
             if (b.data & 0x80000000u) {
                 const uint32_t off = b.data & 0x0FFFFFFFu, cnt = ((b.data >> 28) & 7u) + 1;
                 if ((size_t)off + cnt > m.nf) return ctx->fail(RT_ERR_INVALID, "mesh %u: BVH leaf out of range", mi);
+                data = (b.data & 0xF0000000u) | (tb + off);
                 for (uint32_t k = off; k < off + cnt; ++k) {
                     const uint32_t face = m.bvh_elements[k];
                     if (face >= m.nf) return ctx->fail(RT_ERR_INVALID, "mesh %u: BVH element out of range", mi);
-                    seen[k] = 1;
                     const float *v0 = &m.v[m.f[face * 3] * 3], *v1 = &m.v[m.f[face * 3 + 1] * 3], *v2 = &m.v[m.f[face * 3 + 2] * 3];
-                    tris[(size_t)k * 3] = make_float4(v0[0], v0[1], v0[2], v1[0]);
-                    tris[(size_t)k * 3 + 1] = make_float4(v1[1], v1[2], v2[0], v2[1]);
-                    tris[(size_t)k * 3 + 2] = make_float4(v2[2], __builtin_bit_cast(float, face), 0.0f, 0.0f);
+                    tris[(size_t)(tb + k) * 3] = make_float4(v0[0], v0[1], v0[2], v1[0]);
+                    tris[(size_t)(tb + k) * 3 + 1] = make_float4(v1[1], v1[2], v2[0], v2[1]);
+                    tris[(size_t)(tb + k) * 3 + 2] = make_float4(v2[2], __builtin_bit_cast(float, face), 0.0f, 0.0f);
                 }
             } else {
                 const uint32_t c = b.data & 0x7FFFFFFFu;
                 if (c & 1u) return ctx->fail(RT_ERR_UNSUPPORTED, "mesh %u: BVH child pairs must start at even indices", mi);
+                data = nb + c;
                 stack.push_back({c, lvl + 1});
                 stack.push_back({c + 1, lvl + 1});
             }
+            // bounds = min.xyz, max.xyz; stored interleaved per axis (see bvh_box_fast)
+            bvh[(size_t)(nb + id) * 2] = make_float4(b.bounds[0], b.bounds[3], b.bounds[1], b.bounds[4]);
+            bvh[(size_t)(nb + id) * 2 + 1] = make_float4(b.bounds[2], b.bounds[5], __builtin_bit_cast(float, data), 0.0f);
+            if (id == 1) { roots[mi] = b; roots[mi].data = data; }
+        }
+        // the four-wide form: a record per inner node reached in steps of two levels from the root
+        {
+            const auto pooled = [&](uint32_t id) { return __builtin_bit_cast(uint32_t, bvh[(size_t)(nb + id) * 2 + 1].z); }; // data word, pool numbering
+            const auto is_leaf = [&](uint32_t id) { return (m.bvh_nodes[id].data & 0x80000000u) != 0; };
+            const float inf = std::numeric_limits<float>::infinity();
+            std::vector<std::pair<uint32_t, size_t>> todo; // (binary node, its record)
+            const auto record_of = [&](uint32_t id) -> uint32_t { // data word of binary node `id` in the four-wide form
+                if (is_leaf(id)) return pooled(id);
+                const size_t rec = bvh4.size() / 8;
+                bvh4.resize(bvh4.size() + 8);
+                todo.push_back({id, rec});
+                return (uint32_t)rec;
+            };
+            root4[mi] = record_of(1);
+            while (!todo.empty()) {
+                const auto [id, rec] = todo.back();
+                todo.pop_back();
+                const uint32_t c = m.bvh_nodes[id].data & 0x7FFFFFFFu;
+                uint32_t slots[4], ns = 0;
+                for (uint32_t ch = c; ch < c + 2; ++ch) {
+                    if (is_leaf(ch)) slots[ns++] = ch;
+                    else { const uint32_t g = m.bvh_nodes[ch].data & 0x7FFFFFFFu; slots[ns++] = g; slots[ns++] = g + 1; }
+                }
+                for (uint32_t k = 0; k < 4; ++k) {
+                    if (k < ns) {
+                        const uint32_t word = record_of(slots[k]); // may grow bvh4: index, not pointer
+                        const float4 b0 = bvh[(size_t)(nb + slots[k]) * 2], b1 = bvh[(size_t)(nb + slots[k]) * 2 + 1];
+                        bvh4[rec * 8 + k * 2] = b0;
+                        bvh4[rec * 8 + k * 2 + 1] = make_float4(b1.x, b1.y, __builtin_bit_cast(float, word), 0.0f);
+                    } else { // a box no ray enters
+                        bvh4[rec * 8 + k * 2] = make_float4(inf, inf, inf, inf);
+                        bvh4[rec * 8 + k * 2 + 1] = make_float4(inf, inf, __builtin_bit_cast(float, kNoNode), 0.0f);
+                    }
+                }
+            }
+            if (bvh4.size() / 8 >= ((size_t)1 << 31)) return ctx->fail(RT_ERR_UNSUPPORTED, "scene has too many BVH nodes");
         }
         max_mesh_depth = std::max(max_mesh_depth, (int)depth);
         DMesh &d = dmeshes[mi];
-        d.n_nodes = m.n_bvh_nodes; d.depth = depth;
-        HIP_TRY(ctx, upload(bvh.data(), bvh.size() * sizeof(float4), (const void **)&d.bvh));
-        HIP_TRY(ctx, upload(tris.data(), tris.size() * sizeof(float4), (const void **)&d.tris));
+        d.n_nodes = m.n_bvh_nodes; d.depth = depth; d.root = nb + 1;
         HIP_TRY(ctx, upload(m.fn, (size_t)m.nf * 12, (const void **)&d.fn));
         HIP_TRY(ctx, upload(m.ft, (size_t)m.nf * 12, (const void **)&d.ft));
         HIP_TRY(ctx, upload(m.vn, (size_t)m.nvn * 12, (const void **)&d.vn));
         HIP_TRY(ctx, upload(m.vt, (size_t)m.nvt * 12, (const void **)&d.vt));
+    }
+    const float4 *d_bvh_pool = nullptr, *d_tri_pool = nullptr, *d_bvh4_pool = nullptr;
+    if (sc->n_meshes) {
+        if (bvh4.empty()) bvh4.resize(8, make_float4(0, 0, 0, 0));
+        HIP_TRY(ctx, upload(bvh4.data(), bvh4.size() * sizeof(float4), (const void **)&d_bvh4_pool));
+        HIP_TRY(ctx, upload(bvh.data(), bvh.size() * sizeof(float4), (const void **)&d_bvh_pool));
+        HIP_TRY(ctx, upload(tris.data(), tris.size() * sizeof(float4), (const void **)&d_tri_pool));
+        for (DMesh &d : dmeshes) { d.bvh = d_bvh_pool; d.tris = d_tri_pool; }
+    }
+    // compact node records of the ray-list kernel
+    std::vector<TNode> tnodes(nn);
+    for (uint32_t i = 0; i < nn; ++i) {
+        TNode &t = tnodes[i];
+        memset(&t, 0, sizeof t);
+        memcpy(t.itm, nodes[i].itm, sizeof t.itm);
+        t.meta = (uint32_t)nodes[i].prim | ((uint32_t)nodes[i].depth << 8);
+        if (nodes[i].prim == RT_PRIM_MESH) {
+            const rt_bvh_node &r = roots[nodes[i].mesh];
+            t.root = r.data;
+            t.root4 = root4[nodes[i].mesh];
+            t.box[0] = r.bounds[0]; t.box[1] = r.bounds[3]; t.box[2] = r.bounds[1]; t.box[3] = r.bounds[4]; t.box[4] = r.bounds[2]; t.box[5] = r.bounds[5];
+        }
     }
     // ---- world-space boxes of the object nodes: rays that miss a node's box need not be taken into its space.
     // The reference tests every ray against every object (src/main.cpp:16-89); skipping one whose box the ray misses
@@ -555,7 +631,9 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc)
         } else if (t.type != RT_TEX_CHECKER) return ctx->fail(RT_ERR_INVALID, "texture %u: unknown type %d", i, t.type);
     }
     DScene S{};
-    S.stack_levels = max_mesh_depth < 0 ? 0 : max_mesh_depth + 2;
+    // entries a lane's stack may hold: the binary walk pushes at most two nodes per level of the tree; the four-wide walk
+    // of the ray-list kernel goes down two levels per visit and pushes up to three nodes each time
+    S.stack_levels = max_mesh_depth < 0 ? 0 : std::max(max_mesh_depth + 2, 3 * ((max_mesh_depth + 1) / 2) + 2);
     // LDS holds the first levels of every lane's stack (26 KiB per 256 threads lets six
     // workgroups share a CU's 160 KiB); deeper entries spill to a global array sized
     // for the largest grid any entry point launches
@@ -567,6 +645,14 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc)
 
     HIP_TRY(ctx, ctx->d_nodes.reserve(sizeof(DNode) * nn));
     HIP_TRY(ctx, hipMemcpy(ctx->d_nodes.p, nodes.data(), sizeof(DNode) * nn, hipMemcpyHostToDevice));
+    for (uint32_t i = 0; i < nn; ++i) {
+        tnodes[i].meta |= (uint32_t)(nodes[i].has_children ? 1u : 0u) << 16;
+        memcpy(tnodes[i].wbox, nodes[i].wbox, sizeof tnodes[i].wbox);
+    }
+    HIP_TRY(ctx, ctx->d_tnodes.reserve(sizeof(TNode) * nn));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_tnodes.p, tnodes.data(), sizeof(TNode) * nn, hipMemcpyHostToDevice));
+    S.tnodes = ctx->d_tnodes.as<TNode>();
+    S.bvh_pool = d_bvh_pool; S.tri_pool = d_tri_pool; S.bvh4_pool = d_bvh4_pool;
     HIP_TRY(ctx, ctx->d_meshes.reserve(sizeof(DMesh) * std::max<size_t>(1, dmeshes.size())));
     if (!dmeshes.empty()) HIP_TRY(ctx, hipMemcpy(ctx->d_meshes.p, dmeshes.data(), sizeof(DMesh) * dmeshes.size(), hipMemcpyHostToDevice));
     HIP_TRY(ctx, ctx->d_materials.reserve(sizeof(rt_material) * std::max<uint32_t>(1, sc->n_materials)));
@@ -947,8 +1033,8 @@ int rt_trace_brief(rt_ctx *ctx, const float *rays6, const float *t_max, int n, r
         uint32_t a_n = (uint32_t)n;
         DCounters *a_ctr = ctx->d_counters.as<DCounters>();
         unsigned long long *a_queue = ctx->d_queue.as<unsigned long long>();
-        uint32_t a_chunk = kRayChunk;
-        void *args[] = {&a_scene, &a_io, &a_n, &a_ctr, &a_queue, &a_chunk};
+        uint32_t a_chunk = kRayChunk, a_split = a_n, a_parts = 1;
+        void *args[] = {&a_scene, &a_io, &a_n, &a_ctr, &a_queue, &a_chunk, &a_split, &a_parts};
         HIP_TRY(ctx, hipEventRecord(ctx->evk0, s));
         HIP_TRY(ctx, hipLaunchKernel(fn, grid, dim3(kBlock), args, lds, s));
         HIP_TRY(ctx, hipEventRecord(ctx->evk1, s));
@@ -1007,8 +1093,8 @@ int rt_trace_brief_noalloc(rt_ctx *ctx, const float *d_rays6, const float *d_t_m
     uint32_t a_n = (uint32_t)n;
     DCounters *a_ctr = (DCounters *)(base + kStaticCountersOff);
     unsigned long long *a_queue = (unsigned long long *)(base + kStaticQueueOff);
-    uint32_t a_chunk = kRayChunk;
-    void *args[] = {&a_scene, &a_io, &a_n, &a_ctr, &a_queue, &a_chunk};
+    uint32_t a_chunk = kRayChunk, a_split = a_n, a_parts = 1;
+    void *args[] = {&a_scene, &a_io, &a_n, &a_ctr, &a_queue, &a_chunk, &a_split, &a_parts};
     HIP_TRY(ctx, hipEventRecord(ctx->evk0, s));
     HIP_TRY(ctx, hipLaunchKernel(fn, grid, dim3(kBlock), args, lds, s));
     HIP_TRY(ctx, hipEventRecord(ctx->evk1, s));

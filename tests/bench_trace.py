@@ -97,6 +97,12 @@ def main():
             same = np.array_equal(ref, got["node"])
         print(f"{name:7s} lockstep {len(rays) / ms_ref / 1e6:8.3f} Grays/s ({ms_ref:7.2f} ms)   ray-list {len(rays) / ms / 1e6:8.3f} Grays/s ({ms:7.2f} ms)   identical: {same}")
         if not same:
+            if tm is None:
+                bad = np.flatnonzero((ref["z"].view(np.uint32) != got["t"].view(np.uint32)) | (ref["node"] != got["node"]))
+                print(f"  {len(bad)} of {len(rays)} rays differ; first: ray {bad[0]} lockstep t={ref['z'][bad[0]]!r} node={ref['node'][bad[0]]} ray-list t={got['t'][bad[0]]!r} node={got['node'][bad[0]]}")
+            else:
+                bad = np.flatnonzero(ref != got["node"])
+                print(f"  {len(bad)} of {len(rays)} shadow rays differ; first: ray {bad[0]}")
             sys.exit(1)
 
 
