@@ -44,12 +44,22 @@ WORKLOADS = {
     "mesh_64k_540p_8spp": (250, 128, 960, 540, 8),        # development size
     "mesh_10m_4k_adaptive": (5000, 1000, 3840, 2160, (16, 256)),  # 10M triangles, 4K, 16..256 spp with the variance stop
     # the reference's shipped scene exactly as it renders it: 1280x720, 128 spp, 50 bounces (ms/frame is the number to read)
-    "scene_a_720p_128spp": ("fixture", "scene_a", 1280, 720, 128),
+    "scene_a_720p_128spp": ("cornell", None, 1280, 720, 128),
     # Whitted-style shader (project-12 snapshot): Blinn-Phong + adaptive soft shadows, no recursion
     "spheres_1080p_16spp_whitted": ("spheres", 8, 1920, 1080, 16),
     # photon maps: 10M + 1M photons traced, balanced and gathered from, 16..64 spp adaptive, 5 bounces
     "photon_box_1080p": ("photons", (10_000_000, 1_000_000), 1920, 1080, (16, 64)),
     "photon_box_540p_small": ("photons", (1_000_000, 100_000), 960, 540, (16, 64)),  # development size
+}
+# what `value` is, per workload: the headline line carries BASELINE.json's metric string
+METRICS = {
+    "mesh_1m_1080p_64spp": "Mrays/sec (whole node) at 1/2/4/8 MI355X, 1M-tri 1080p",
+    "mesh_64k_540p_8spp": "Mrays/sec, 64k-tri 540p 8 spp path tracing (development size)",
+    "mesh_10m_4k_adaptive": "Mrays/sec, 10M-tri 4K adaptive 16..256 spp path tracing",
+    "scene_a_720p_128spp": "Mrays/sec, scene.xml as shipped (1280x720, 128 spp); ms_per_step is ms/frame scene.xml",
+    "spheres_1080p_16spp_whitted": "Mrays/sec, sphere/plane scene 1080p 16 spp, Blinn-Phong + shadows",
+    "photon_box_1080p": "Mrays/sec, photon-mapped caustics scene 1080p, 10M + 1M photons traced and gathered",
+    "photon_box_540p_small": "Mrays/sec, photon-mapped caustics scene 540p, 1M + 0.1M photons (development size)",
 }
 MESHES = {}  # generated meshes by workload, kept for the reference baseline (it reads the OBJ text)
 B_PHOTON = 32  # a kd-tree node visit reads one 32-byte photon record; a stored photon writes one
@@ -61,14 +71,11 @@ def build_scene(name):
     spp = spp if isinstance(spp, tuple) else (spp, spp)
     if kind == "spheres":
         return lib.HostScene.from_string(scenes.spheres_scene_xml(grid=arg, width=w, height=h)), w, h, spp, 0, abi.RT_MODE_WHITTED, 0, None
-    if kind == "fixture":
-        hs = abi.scene_from_fixture(dict(np.load(os.path.join(ROOT, "tests", "golden", arg + ".npz"))))
-        hs.camera.width, hs.camera.height = w, h
-        return hs, w, h, spp, 0, abi.RT_MODE_PATH, 50, None
+    if kind == "cornell":
+        return lib.HostScene.from_string(scenes.cornell_scene_xml(w, h)), w, h, spp, 0, abi.RT_MODE_PATH, 50, None
     if kind == "photons":
-        # the reference's own scene (its Cornell box with mirror, glass and glossy spheres), held as a flattened fixture
-        hs = abi.scene_from_fixture(dict(np.load(os.path.join(ROOT, "tests", "golden", "scene_a.npz"))))
-        hs.camera.width, hs.camera.height = w, h
+        # the reference's own scene: its Cornell box with mirror, glass and glossy spheres
+        hs = lib.HostScene.from_string(scenes.cornell_scene_xml(w, h))
         pp = abi.PhotonParams(flags=abi.RT_PM_INDIRECT | abi.RT_PM_CAUSTICS, n_global=arg[0], n_caustic=arg[1], max_segments=64, seed=7)
         return hs, w, h, spp, 0, abi.RT_MODE_WHITTED, 5, pp
     mesh = scenes.heightfield(kind, arg)
@@ -270,7 +277,7 @@ def main():
 
     if rank == 0:
         n_launch = max(1, counted.trace_launches)
-        kernel = {abi.RT_MODE_PATH: "k_paths", abi.RT_MODE_WHITTED: "k_whitted"}[mode]
+        kernel = "k_rays" if counted.trace_pipeline == 1 else {abi.RT_MODE_PATH: "k_paths", abi.RT_MODE_WHITTED: "k_whitted"}[mode]
         flops_launch = algorithmic_flops(hs.desc, counted, mode) / n_launch
         bytes_launch = (algorithmic_bytes(counted, w * h // world) + B_PHOTON * counted.photon_visits) / n_launch
         avg_launch_s = kernel_ms / max(1, launches) / 1e3
@@ -286,7 +293,7 @@ def main():
         mem_bound = ntri > 0 or pp is not None
         first, second, second_key = (hbm, valu, "valu_fp32") if mem_bound else (valu, hbm, "hbm")
         out = {
-            "metric": "Mrays/sec (whole node) at 1/2/4/8 MI355X, 1M-tri 1080p",
+            "metric": METRICS[args.workload],
             "value": rays_per_frame * args.steps / dt / 1e6,
             "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -302,6 +309,7 @@ def main():
                        "camera_paths_per_frame": int(stats[2].item())},
             "roofline": dict(first, bound="hbm" if mem_bound else "valu_fp32", traffic=traffic, traffic_source=traffic_src,
                              kernel=kernel, avg_launch_ms=avg_launch_s * 1e3, launches_per_frame=n_launch,
+                             kernel_ms_per_frame=kernel_ms / args.steps,
                              box_tests_per_frame=int(stats[3].item()), tri_tests_per_frame=int(stats[4].item()),
                              note="rank 0's launches; algorithmic bytes and flops from the kernels' own ray/box/triangle/photon counters",
                              **{second_key: second}),

@@ -221,8 +221,9 @@ typedef struct rt_counters {
     uint64_t gathers;       /* irradiance estimates (photon-map lookups) */
     uint64_t photon_visits; /* kd-tree nodes visited by them (counting variant only) */
     double kernel_ms;       /* GPU time of the last rt_render, HIP events on the render stream */
-    double trace_kernel_ms; /* of which: the path-tracing kernel(s) */
-    uint32_t trace_launches;
+    double trace_kernel_ms; /* of which: the dominant kernel's launches (k_paths / k_whitted; the ray-list kernel k_rays in the wavefront pipeline) */
+    uint32_t trace_launches; /* how many such launches */
+    uint32_t trace_pipeline; /* 0 = lock-step kernel (one launch per sampling round), 1 = wavefront pipeline (one k_rays launch per bounce) */
     uint64_t phase_cycles[16]; /* diagnostic builds only (RT_PROFILE_PHASES): per kernel phase wave clocks [0..3], executions [4..7], active lanes [8..11] */
 } rt_counters;
 

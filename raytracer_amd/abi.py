@@ -108,7 +108,8 @@ class Counters(C.Structure):
     _fields_ = [("closest_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("camera_paths", C.c_uint64),
                 ("box_tests", C.c_uint64), ("tri_tests", C.c_uint64), ("gathers", C.c_uint64),
                 ("photon_visits", C.c_uint64), ("kernel_ms", C.c_double),
-                ("trace_kernel_ms", C.c_double), ("trace_launches", C.c_uint32), ("phase_cycles", C.c_uint64 * 16)]
+                ("trace_kernel_ms", C.c_double), ("trace_launches", C.c_uint32), ("trace_pipeline", C.c_uint32),
+                ("phase_cycles", C.c_uint64 * 16)]
 
 
 HIT_DTYPE = np.dtype([("z", "<f4"), ("p", "<f4", 3), ("n", "<f4", 3), ("uvw", "<f4", 3),

@@ -67,6 +67,9 @@ RT_DEV void flush_counters(DCounters *ctr, const PathTally &pt, const Tally<COUN
         for (int i = 0; i < 16; ++i) atomicAdd(&ctr->phase[i], pt.ph[i]); // lane 0's clocks stand for the wave
 #endif
     }
+#ifdef RT_CULL_CHECK
+    { const uint64_t cv = wave_sum(tl.cull_violations); if ((threadIdx.x & 63) == 0) atomicAdd(&ctr->phase[11], (unsigned long long)cv); }
+#endif
 #ifdef RT_PROFILE_LANES
     for (int i = 0; i < 8; ++i) {
         const uint64_t wv = wave_sum(tl.wave[i]), ln = wave_sum(tl.lanes[i]);
@@ -126,8 +129,7 @@ RT_DEV Ray camera_ray(const DFrame &F, const float *halton, int i, int j, int k,
 constexpr uint32_t kChunk = RT_CHUNK;
 constexpr uint32_t kQueues = RT_QUEUES;
 constexpr uint32_t kQueueStride = 16; // unsigned long longs between queue words (128 bytes)
-constexpr uint32_t kMaxRayParts = 8; // parts of a ray list (k_rays), one queue word each
-constexpr size_t kQueueBytes = (kQueues > kMaxRayParts ? kQueues : kMaxRayParts) * kQueueStride * sizeof(unsigned long long);
+constexpr size_t kQueueBytes = kQueues * kQueueStride * sizeof(unsigned long long);
 
 struct WorkQueue {
     unsigned long long *words;

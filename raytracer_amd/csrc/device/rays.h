@@ -25,6 +25,7 @@ namespace rtd {
 // hit = closest: (t, node id bits, face | front << 31, u), hit_v = v;  any-hit: (1 or 0, 0, 0, 0)
 struct NoPending {};
 struct RayListIO {
+    static constexpr bool kWide = false; // the reference's binary walk
     static constexpr bool kDeferShadow = false;
     typedef NoPending Pending;
     RT_DEV void begin_put_shadow(uint32_t, Pending &) const {}
@@ -50,6 +51,7 @@ struct RayListIO {
 // The same list read and answered in the caller's own formats (six floats per ray, an optional t_max array,
 // rt_hit_brief records): nothing to convert on the host, so an entry point built on it needs no staging buffers.
 struct BriefIO {
+    static constexpr bool kWide = false;
     static constexpr bool kDeferShadow = false;
     typedef NoPending Pending;
     RT_DEV void begin_put_shadow(uint32_t, Pending &) const {}
@@ -103,8 +105,11 @@ template <bool COUNT, int LEVELS, class IO> struct RayWalker {
     // walk, the same triangles: a leaf is reached if and only if the ray enters every box above it, and a box lies
     // inside its parent's.  What can differ from the reference's order is which of several triangles hit at exactly the
     // same distance is reported; t and the node never do.  The counting variant walks the binary tree, as the reference
-    // does: its box and triangle counts are the reference's.
-    static constexpr bool kWide = !COUNT;
+    // does: its box and triangle counts are the reference's.  So do the batch query entry points, whose answers are the
+    // reference's to the last bit: with two hits an ulp apart the order of the walk can decide which box is still
+    // entered "before the closest hit so far" (one camera ray in twelve million of the 1M-triangle scene came back
+    // one ulp farther through the wide walk).
+    static constexpr bool kWide = IO::kWide && !COUNT;
     bool active = false, any_hit = false, in_bvh = false;
     bool unoccluded = false;             // a finished shadow ray whose answer the IO has not been told yet (retire())
     uint32_t tag = 0;                    // the list entry as the IO names it
@@ -342,16 +347,12 @@ template <bool COUNT, int LEVELS, class IO> struct RayWalker {
     }
 };
 
-// The list is handed out in chunks of ray_chunk entries, one atomic per chunk and wave.  With parts > 1 the list is cut
-// into that many parts with a queue word each (128 bytes apart): part p holds the p-th slice of the entries before
-// n_split and the p-th slice of the entries after it (for the path tracer: extension rays and shadow rays of the same
-// region of the image).  Workgroup b starts on part b % parts - workgroups are dealt to the eight XCDs round-robin, so
-// with eight parts each XCD's L2 sees the rays, and with them the BVH nodes, of one eighth of the list - and goes on to
-// the next part when its own is used up.
+// The list is handed out in chunks of ray_chunk entries, one atomic per chunk and wave.  (Cutting the list into
+// eight parts with a queue word each, so that each XCD's L2 sees the rays of one eighth of the image, was measured:
+// 88.6 against 89.0 ms of ray launches per 1080p frame, not worth the index arithmetic in the refill step.)
 template <bool COUNT, int LEVELS, class IO>
 __global__ __launch_bounds__(kBlock, RT_RAYS_MIN_WAVES) void k_rays(DScene S, IO io, uint32_t n_rays, DCounters *ctr,
-                                                                  unsigned long long *queue, uint32_t ray_chunk,
-                                                                  uint32_t n_split, uint32_t parts)
+                                                                  unsigned long long *queue, uint32_t ray_chunk)
 {
     extern __shared__ uint32_t lds[];
     const LaneStack st = lane_stack(lds, S);
@@ -360,13 +361,9 @@ __global__ __launch_bounds__(kBlock, RT_RAYS_MIN_WAVES) void k_rays(DScene S, IO
     Tally<COUNT> tl;
     RayWalker<COUNT, LEVELS, IO> w;
 
-    // wave-uniform window of the ray list: entries [chunk_next, chunk_end) of part q (part-local numbering)
+    // wave-uniform window of the ray list
     uint32_t chunk_next = 0, chunk_end = 0;
     bool exhausted = false;
-    uint32_t q = blockIdx.x % parts, tried = 0;
-    const uint32_t n_first = n_split < n_rays ? n_split : n_rays, n_second = n_rays - n_first;
-    // slice p of a range of n entries: [p * n / parts, (p + 1) * n / parts)
-    auto slice = [parts](uint32_t n, uint32_t p) { return (uint32_t)((uint64_t)n * p / parts); };
 
     // A lane is idle, stepping through the scene nodes, walking a BVH, or parked at a leaf.  The wave
     // runs each kind of step for all lanes that wait for it at once, and lets lanes wait until enough
@@ -378,14 +375,13 @@ __global__ __launch_bounds__(kBlock, RT_RAYS_MIN_WAVES) void k_rays(DScene S, IO
         const uint64_t idle = __ballot(!w.active);
         pt.tock(12);
         if (idle != 0 && !exhausted && ((uint32_t)__popcll(idle) >= (uint32_t)RT_RAYS_REFILL_MIN_LANES || !__any(w.in_bvh))) {
-            while (chunk_next >= chunk_end && !exhausted) {
+            if (chunk_next >= chunk_end) {
                 unsigned long long b = 0;
-                if (lane == 0) b = atomicAdd(&queue[q * kQueueStride], (unsigned long long)ray_chunk);
+                if (lane == 0) b = atomicAdd(queue, (unsigned long long)ray_chunk);
                 b = __shfl(b, 0, 64);
-                const uint32_t len = (slice(n_first, q + 1) - slice(n_first, q)) + (slice(n_second, q + 1) - slice(n_second, q));
-                if (b < len) { chunk_next = (uint32_t)b; chunk_end = b + ray_chunk < len ? (uint32_t)(b + ray_chunk) : len; }
-                else if (++tried >= parts) exhausted = true;
-                else q = (q + 1) % parts;
+                chunk_next = b < n_rays ? (uint32_t)b : n_rays;
+                chunk_end = b + ray_chunk < n_rays ? (uint32_t)(b + ray_chunk) : n_rays;
+                if (chunk_next >= chunk_end) exhausted = true;
             }
             const uint32_t avail = chunk_end - chunk_next;
             const uint32_t want = (uint32_t)__popcll(idle);
@@ -396,8 +392,7 @@ __global__ __launch_bounds__(kBlock, RT_RAYS_MIN_WAVES) void k_rays(DScene S, IO
             const bool owes = IO::kDeferShadow && !w.active && w.unoccluded;
             if (owes) io.begin_put_shadow(w.tag, pend);
             if (taking) {
-                const uint32_t i = chunk_next + rank, first_len = slice(n_first, q + 1) - slice(n_first, q);
-                const uint32_t e = i < first_len ? slice(n_first, q) + i : n_first + slice(n_second, q) + (i - first_len);
+                const uint32_t e = chunk_next + rank;
                 float4 o, d; bool shadow; float tmax; uint32_t tg;
                 const uint32_t old = w.tag;
                 const bool got = io.fetch(e, o, d, shadow, tmax, tg); // a list may have holes

@@ -68,6 +68,9 @@ struct LaneStack {
 
 template <bool COUNT> struct Tally {
     uint32_t box = 0, tri = 0;
+#ifdef RT_CULL_CHECK
+    uint32_t cull_violations = 0; // diagnostic build: objects the wave skipped although this lane's own box test said "reaches"
+#endif
     RT_DEV void boxes(uint32_t n) { if (COUNT) box += n; }
     RT_DEV void tris(uint32_t n) { if (COUNT) tri += n; }
 #ifdef RT_PROFILE_LANES
@@ -403,14 +406,8 @@ RT_DEV bool reaches_box(const float *b, V3 p, V3 inv, float t_max)
 // first hit in depth-first order with the smallest z (strict <), which is what
 // the reference's per-level comparisons select.
 // With CULL an object none of the wave's rays can reach (its world-space box is missed, or lies behind the closest
-// hit so far: t is the same in every node's space) is skipped by the whole wave.
-// NOT USED BY DEFAULT.  The vote made the 64-sphere Whitted frame 1.5 x faster and its frames were bit-exact in every
-// test for a while, but the result depends on how the compiler lays out the kernel around the vote: with two votes per
-// node (one on either side of the matrix load) 162 pixels of a 200x112 frame lost their nearest object, and after an
-// unrelated change elsewhere in the library the depth plane of a 96x54 frame took 316 values of other samples of the
-// same pixels while the vote in trace_shadow() was compiled in (not with the one in trace_closest() alone).  The
-// per-lane arithmetic cannot do either; until the control flow around the vote is understood the kernels are built
-// without it (RT_WHITTED_CULL=1 builds it in).
+// hit so far: t is the same in every node's space) is skipped by the whole wave: one vote per node, taken by all lanes
+// that are in the query, none of which leaves the node loop before its end.
 template <bool COUNT, int LEVELS, bool CULL = false>
 RT_DEV bool trace_closest(const DScene &S, Ray ray, LaneStack st, Hit &h, Tally<COUNT> &tl)
 {
@@ -423,7 +420,11 @@ RT_DEV bool trace_closest(const DScene &S, Ray ray, LaneStack st, Hit &h, Tally<
         const DNode &nd = S.nodes[i];
         const int d = nd.depth;
         // one vote per node: does any ray of the wave reach the object's box?
-        const bool skip = CULL && (nd.prim == RT_PRIM_NONE || !__any(reaches_box(nd.wbox, ray.p, winv, h.z)));
+        const bool reach = CULL && reaches_box(nd.wbox, ray.p, winv, h.z);
+        const bool skip = CULL && (nd.prim == RT_PRIM_NONE || !__any(reach));
+#ifdef RT_CULL_CHECK
+        if (CULL && skip && nd.prim != RT_PRIM_NONE && reach) ++tl.cull_violations;
+#endif
         if (skip && !nd.has_children) continue;
         const Ray parent = (d == 0) ? ray : lv.get(d - 1);
         const Ray lr = to_node(nd, parent);
@@ -507,7 +508,10 @@ RT_DEV void finish_hit(const DScene &S, Ray ray, Hit &h, bool want_uvw)
     }
 }
 
-// shootShadowRay (src/main.cpp:72-89,122-125): any hit with t < t_max
+// shootShadowRay (src/main.cpp:72-89,122-125): any hit with t < t_max.
+// Without CULL a lane leaves at its first occluder.  With CULL the lanes vote per node, so they stay in the node loop
+// together: a lane that has found its occluder idles until every lane has one or the list ends (the vote is then
+// taken by the same set of lanes at every node, and no lane returns from inside the loop).
 template <bool COUNT, int LEVELS, bool CULL = false>
 RT_DEV bool trace_shadow(const DScene &S, Ray ray, float t_max, LaneStack st, Tally<COUNT> &tl)
 {
@@ -515,23 +519,37 @@ RT_DEV bool trace_shadow(const DScene &S, Ray ray, float t_max, LaneStack st, Ta
     lv.init(ray);
     const V3 winv = CULL ? cull_inverse(ray.d) : ray.d;
     const int n = S.n_nodes;
+    bool occluded = false;
     for (int i = 0; i < n; ++i) {
         const DNode &nd = S.nodes[i];
         const int d = nd.depth;
-        const bool skip = CULL && (nd.prim == RT_PRIM_NONE || !__any(reaches_box(nd.wbox, ray.p, winv, t_max)));
+        const bool reach = CULL && !occluded && reaches_box(nd.wbox, ray.p, winv, t_max);
+        const bool skip = CULL && (nd.prim == RT_PRIM_NONE || !__any(reach));
+#ifdef RT_CULL_CHECK
+        if (CULL && skip && nd.prim != RT_PRIM_NONE && reach) ++tl.cull_violations;
+#endif
         if (skip && !nd.has_children) continue;
         const Ray parent = (d == 0) ? ray : lv.get(d - 1);
         const Ray lr = to_node(nd, parent);
         if (nd.has_children) lv.set(d, lr);
         const int prim = nd.prim;
         if (prim == RT_PRIM_NONE || skip) continue;
-        bool occ;
-        if (prim == RT_PRIM_SPHERE) occ = sphere_shadow(lr, t_max);
-        else if (prim == RT_PRIM_PLANE) occ = plane_shadow(lr, t_max);
-        else occ = mesh_shadow<COUNT>(S.meshes[nd.mesh], lr, t_max, st, tl);
-        if (occ) return true;
+        if (CULL) {
+            if (!occluded) {
+                if (prim == RT_PRIM_SPHERE) occluded = sphere_shadow(lr, t_max);
+                else if (prim == RT_PRIM_PLANE) occluded = plane_shadow(lr, t_max);
+                else occluded = mesh_shadow<COUNT>(S.meshes[nd.mesh], lr, t_max, st, tl);
+            }
+            if (__all(occluded)) break;
+        } else {
+            bool occ;
+            if (prim == RT_PRIM_SPHERE) occ = sphere_shadow(lr, t_max);
+            else if (prim == RT_PRIM_PLANE) occ = plane_shadow(lr, t_max);
+            else occ = mesh_shadow<COUNT>(S.meshes[nd.mesh], lr, t_max, st, tl);
+            if (occ) return true;
+        }
     }
-    return false;
+    return occluded;
 }
 
 } // namespace rtd

@@ -16,8 +16,11 @@
 //                  wave (4 M of them on the first bounce of a 1080p x 64 spp round, all on one address) took longer
 //                  than the shading itself.
 //
-// A path's random stream, draw order and every floating-point expression are those of path_step(): the frames are
-// bit-identical to the lock-step kernel's.  Additions to an accumulator happen in the path's own order: the
+// A path's random stream, draw order and every floating-point expression are those of path_step().  The rays go
+// through the four-wide walk of the ray-list kernel, which can report a hit one ulp away from the binary walk's when
+// two triangles are hit within an ulp of each other (about one ray in ten million); the depth and id planes therefore
+// do not come from these rays but from k_planes, which sends the first sample's camera ray of every pixel through the
+// reference's binary walk (trace_closest).  Additions to an accumulator happen in the path's own order: the
 // next-event term of vertex b is added by the ray launch that follows k_wf_shade(b), before k_wf_shade(b+1) adds what
 // the path finds at vertex b+1.
 #pragma once
@@ -42,6 +45,7 @@ struct WfState {
 // ray list of k_rays: entries [0, n_ext) are the extension rays of the slots the queue names (slot e itself without a
 // queue: the camera rays), entries [n_ext, n_ext + n_shadow) the shadow rays of the slots the shadow queue names
 struct WfIO {
+    static constexpr bool kWide = true; // four-wide BVH walk: the depth / id planes come from k_planes, not from these rays
     static constexpr bool kDeferShadow = true;
     struct Pending { float4 c, a; };
     WfState P;
@@ -97,6 +101,29 @@ __global__ __launch_bounds__(kBlock) void k_wf_generate(DFrame F, const float *_
         const Ray r = camera_ray(F, halton, pix % F.width, pix / F.width, k, off);
         P.ray_o[item] = make_float4(r.p.x, r.p.y, r.p.z, 1.0f);
         P.ray_d[item] = make_float4(r.d.x, r.d.y, r.d.z, __uint_as_float(0u));
+    }
+}
+
+// depth / id planes of a round that starts at sample 0: the first sample's camera ray of every listed pixel, through the
+// reference's own walk order (trace_closest) - bit for bit what the reference's TraceRay returns
+template <int LEVELS>
+__global__ __launch_bounds__(kBlock) void k_planes(DScene S, DFrame F, const float *__restrict__ halton,
+                                                   const int32_t *__restrict__ active, uint32_t n_active, FramePlanes out)
+{
+    extern __shared__ uint32_t lds[];
+    const LaneStack st = lane_stack(lds, S);
+    for (uint32_t a = blockIdx.x * kBlock + threadIdx.x; a < n_active; a += gridDim.x * kBlock) {
+        const int pix = active[a];
+        Rng rng;
+        rng_set_sequence(rng, 0, pixel_seed(F.seed, (uint64_t)pix));
+        float off[4];
+        off[0] = rng_float(rng); off[1] = rng_float(rng); off[2] = rng_float(rng); off[3] = rng_float(rng);
+        const Ray ray = camera_ray(F, halton, pix % F.width, pix / F.width, 0, off);
+        Hit h;
+        Tally<false> none;
+        const bool hit = trace_closest<false, LEVELS>(S, ray, st, h, none);
+        if (out.z) out.z[pix] = h.z;
+        if (out.object_id) out.object_id[pix] = hit ? h.node : -1;
     }
 }
 
@@ -160,11 +187,6 @@ __global__ __launch_bounds__(kBlock) void k_wf_shade(DScene S, DFrame F, const i
             h.face = ff & 0x7FFFFFFFu; h.front = (int)(ff >> 31);
             h.u = hr.w; h.v = P.hit_v[slot];
             const bool hit = h.node != -1;
-            if (FIRST && k == 0) { // depth / id planes: the first sample's camera ray
-                const int pix = active[a];
-                if (out.z) out.z[pix] = h.z;
-                if (out.object_id) out.object_id[pix] = hit ? h.node : -1;
-            }
             V3 add = mk(0.0f, 0.0f, 0.0f);
             bool adds = false;
             if (!hit) { // main.cpp:175-176

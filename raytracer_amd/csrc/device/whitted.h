@@ -25,7 +25,7 @@ namespace rtd {
 #define RT_WHITTED_MIN_WAVES 4 // waves per SIMD the register allocator must leave room for
 #endif
 #ifndef RT_WHITTED_CULL
-#define RT_WHITTED_CULL 0 // 1: skip objects whose world-space box no ray of the wave reaches (see trace_closest: not trusted yet)
+#define RT_WHITTED_CULL 1 // skip objects whose world-space box no ray of the wave reaches (trace_closest / trace_shadow); 0 builds the votes out
 #endif
 constexpr bool kWhittedCull = RT_WHITTED_CULL != 0;
 constexpr int kGatherQuorum = RT_GATHER_QUORUM; // parked lanes that start a round of photon lookups

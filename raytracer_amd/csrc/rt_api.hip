@@ -79,7 +79,6 @@ struct rt_ctx {
     DeviceBuf d_wf_state, d_wf_queue[2], d_wf_sh_queue, d_wf_counts;
     static constexpr int kMaxRayLaunches = 96;
     hipEvent_t ray_ev[2 * kMaxRayLaunches] = {};
-    int ray_parts = 8; // RT_RAY_PARTS: parts the ray lists of the large launches are cut into, one per XCD (1..8)
     int pipeline = -1; // RT_PIPELINE: 0 = lock-step path kernel (k_paths), 1 = wavefront; -1: chosen per scene (wavefront when it has meshes)
     size_t ovf_threads = 0;
     int lds_levels_max = 13;
@@ -253,6 +252,18 @@ static int render_wavefront(rt_ctx *ctx, const DFrame &F, const int32_t *act, ui
     P.sh_o = (float4 *)(base + offs[6]); P.sh_d = (float4 *)(base + offs[7]); P.sh_c = (float4 *)(base + offs[8]);
     P.acc = ctx->d_sbuf.as<float4>();
 
+    if (k0 == 0 && (planes.z || planes.object_id)) { // depth / id planes: the first samples' camera rays through the reference's walk
+        const uint32_t n_px = items / (uint32_t)nk;
+        const void *fp = ctx->ray_levels <= 1 ? (const void *)k_planes<1> : ctx->ray_levels == 2 ? (const void *)k_planes<2> : (const void *)k_planes<5>;
+        const dim3 grid((unsigned)std::min<uint64_t>(((uint64_t)n_px + kBlock - 1) / kBlock, ctx->ovf_threads / kBlock));
+        DScene p_scene = ctx->scene;
+        DFrame p_frame = F;
+        const float *p_hal = ctx->d_halton.as<float>();
+        uint32_t p_n = n_px;
+        FramePlanes p_planes = planes;
+        void *pargs[] = {&p_scene, &p_frame, &p_hal, &act, &p_n, &p_planes};
+        HIP_TRY(ctx, hipLaunchKernel(fp, grid, dim3(kBlock), pargs, lds, s));
+    }
     const dim3 wide((unsigned)std::min<uint64_t>(((uint64_t)items + kBlock - 1) / kBlock, (uint64_t)ctx->n_cu * 32));
     hipLaunchKernelGGL(k_wf_generate, wide, dim3(kBlock), 0, s, F, ctx->d_halton.as<float>(), act, items, k0, nk, P);
     HIP_TRY(ctx, hipGetLastError());
@@ -278,8 +289,7 @@ static int render_wavefront(rt_ctx *ctx, const DFrame &F, const int32_t *act, ui
             // rays a wave reserves at a time: few atomics on the queue word in the large launches, enough chunks for every wave in the small ones
             const uint64_t per_wave = n_rays / ((uint64_t)grid.x * (kBlock / 64)) / 8;
             uint32_t a_chunk = per_wave >= 1024 ? 1024u : per_wave >= 512 ? 512u : per_wave >= 256 ? 256u : per_wave >= 128 ? 128u : 64u;
-            uint32_t a_split = n_ext, a_parts = n_rays >= (1u << 20) ? (uint32_t)ctx->ray_parts : 1u;
-            void *targs[] = {&a_scene, &a_io, &a_n, &a_ctr, &a_queue, &a_chunk, &a_split, &a_parts};
+            void *targs[] = {&a_scene, &a_io, &a_n, &a_ctr, &a_queue, &a_chunk};
             HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue.p, 0, kQueueBytes, s));
             const bool timed = launch < rt_ctx::kMaxRayLaunches;
             if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ray_ev[2 * launch], s));
@@ -354,6 +364,7 @@ int rt_init(int device, rt_ctx **out)
                           (const void *)k_whitted<false, 1>, (const void *)k_whitted<false, 2>, (const void *)k_whitted<false, 5>,
                           (const void *)k_whitted<true, 1>, (const void *)k_whitted<true, 2>, (const void *)k_whitted<true, 5>,
                           (const void *)k_probe<1>, (const void *)k_probe<2>, (const void *)k_probe<5>,
+                          (const void *)k_planes<1>, (const void *)k_planes<2>, (const void *)k_planes<5>,
                           (const void *)k_order_keys<1>, (const void *)k_order_keys<2>, (const void *)k_order_keys<5>,
                           (const void *)k_trace, (const void *)k_trace_shadow, (const void *)k_trace_paths})
         (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -366,7 +377,6 @@ int rt_init(int device, rt_ctx **out)
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
     ctx->n_cu = prop.multiProcessorCount;
-    if (const char *e9 = getenv("RT_RAY_PARTS")) ctx->ray_parts = std::max(1, std::min(8, atoi(e9)));
     if (const char *e3 = getenv("RT_PIPELINE")) ctx->pipeline = strcmp(e3, "wave") == 0 ? 1 : strcmp(e3, "mega") == 0 ? 0 : -1;
     for (hipEvent_t &ev : ctx->ray_ev)
         if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
@@ -929,7 +939,7 @@ int rt_render(rt_ctx *ctx, const rt_render_params *prm, rt_frame_out *out)
     c.box_tests = dc.box_tests; c.tri_tests = dc.tri_tests;
     c.gathers = dc.gathers; c.photon_visits = dc.photon_visits;
     for (int i = 0; i < 16; ++i) c.phase_cycles[i] = dc.phase[i];
-    c.kernel_ms = ms; c.trace_kernel_ms = trace_ms; c.trace_launches = launches;
+    c.kernel_ms = ms; c.trace_kernel_ms = trace_ms; c.trace_launches = launches; c.trace_pipeline = wavefront ? 1u : 0u;
     return RT_OK;
 }
 
@@ -1033,8 +1043,8 @@ int rt_trace_brief(rt_ctx *ctx, const float *rays6, const float *t_max, int n, r
         uint32_t a_n = (uint32_t)n;
         DCounters *a_ctr = ctx->d_counters.as<DCounters>();
         unsigned long long *a_queue = ctx->d_queue.as<unsigned long long>();
-        uint32_t a_chunk = kRayChunk, a_split = a_n, a_parts = 1;
-        void *args[] = {&a_scene, &a_io, &a_n, &a_ctr, &a_queue, &a_chunk, &a_split, &a_parts};
+        uint32_t a_chunk = kRayChunk;
+        void *args[] = {&a_scene, &a_io, &a_n, &a_ctr, &a_queue, &a_chunk};
         HIP_TRY(ctx, hipEventRecord(ctx->evk0, s));
         HIP_TRY(ctx, hipLaunchKernel(fn, grid, dim3(kBlock), args, lds, s));
         HIP_TRY(ctx, hipEventRecord(ctx->evk1, s));
@@ -1093,8 +1103,8 @@ int rt_trace_brief_noalloc(rt_ctx *ctx, const float *d_rays6, const float *d_t_m
     uint32_t a_n = (uint32_t)n;
     DCounters *a_ctr = (DCounters *)(base + kStaticCountersOff);
     unsigned long long *a_queue = (unsigned long long *)(base + kStaticQueueOff);
-    uint32_t a_chunk = kRayChunk, a_split = a_n, a_parts = 1;
-    void *args[] = {&a_scene, &a_io, &a_n, &a_ctr, &a_queue, &a_chunk, &a_split, &a_parts};
+    uint32_t a_chunk = kRayChunk;
+    void *args[] = {&a_scene, &a_io, &a_n, &a_ctr, &a_queue, &a_chunk};
     HIP_TRY(ctx, hipEventRecord(ctx->evk0, s));
     HIP_TRY(ctx, hipLaunchKernel(fn, grid, dim3(kBlock), args, lds, s));
     HIP_TRY(ctx, hipEventRecord(ctx->evk1, s));

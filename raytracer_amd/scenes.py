@@ -116,6 +116,43 @@ def mesh_scene_xml(obj_name="mesh_1m.obj", width=1920, height=1080):
 """
 
 
+def cornell_scene_xml(width=1280, height=720):
+    """The scene the reference ships with (its only one): a closed box of five walls around a mirror, a glass and a
+    glossy sphere, one spherical light under the ceiling.  Written out from the tables below; the host-side tests
+    check that the library's reader turns this text into exactly the arrays the reference's loader produced for its
+    own file."""
+    walls = (("WallBottom", "wall", None, "z", -12), ("WallTop", "wall", (180, "x"), "z", 12),
+             ("WallBack", "wall", (90, "x"), "y", 20), ("WallLeft", "wallRed", (90, "y"), "x", -15),
+             ("WallRight", "wallGreen", (-90, "y"), "x", 15))
+    spheres = (("sphere1", "reflective", 6, (0, 4, 6)), ("sphere2", "refractive", 5, (9, -3, 5)), ("sphere3", "smooth", 5, (-9, -3, 5)))
+    out = ["<xml>", "  <scene>", '    <object name="box">', '      <translate x="0" y="0" z="12"/>']
+    for name, mtl, rot, axis, off in walls:
+        out.append(f'      <object type="plane" name="{name}" material="{mtl}">')
+        out.append('        <scale value="32"/>')
+        if rot:
+            out.append(f'        <rotate angle="{rot[0]}" {rot[1]}="1"/>')
+        out.append(f'        <translate {axis}="{off}"/>')
+        out.append("      </object>")
+    out.append("    </object>")
+    for name, mtl, r, (x, y, z) in spheres:
+        out += [f'    <object type="sphere" name="{name}" material="{mtl}">', f'      <scale value="{r}"/>',
+                f'      <translate x="{x}" y="{y}" z="{z}"/>', "    </object>"]
+    for name, rgb in (("wall", (1, 1, 1)), ("wallRed", (1.0, 0.2, 0.2)), ("wallGreen", (0.2, 1.0, 0.2))):
+        out += [f'    <material type="blinn" name="{name}">',
+                f'      <diffuse r="{rgb[0]}" g="{rgb[1]}" b="{rgb[2]}" value="0.7"/>', '      <specular value="0"/>', "    </material>"]
+    out += ['    <material type="blinn" name="reflective"><diffuse value="0"/><specular value="0.9"/><glossiness value="128"/>'
+            '<reflection value="0.9"/></material>',
+            '    <material type="blinn" name="refractive"><diffuse value="0"/><specular value="0"/><glossiness value="1024"/>'
+            '<refraction value="0.9" index="1.52"/></material>',
+            '    <material type="blinn" name="smooth"><diffuse value="0.7"/><specular value="0.3"/><glossiness value="64"/></material>',
+            '    <light type="point" name="pointLight"><intensity value="500"/><position x="0" y="0" z="18"/>'
+            '<size value="1"/><attenuation value="1"/></light>',
+            "  </scene>", '  <camera gamma="sRGB">', '    <position x="0" y="-60" z="12"/>', '    <target x="0" y="0" z="12"/>',
+            '    <up x="0" y="0" z="1"/>', '    <fov value="30"/>', f'    <width value="{width}"/>', f'    <height value="{height}"/>',
+            "  </camera>", "</xml>", ""]
+    return "\n".join(out)
+
+
 class _PCG32:
     """PCG32 with the reference's one-argument seeding (src/rng.h:34,38,90-98); scene generation only."""
     M = 0x5851F42D4C957F2D

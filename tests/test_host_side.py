@@ -88,6 +88,14 @@ def test_xml_reader_matches_reference_loader(name):
     check_scene_against_dump(hs, g)
 
 
+def test_generated_cornell_scene_is_the_references_scene():
+    """raytracer_amd.scenes.cornell_scene_xml (what bench.py renders as `scene_a`) against the reference loader's dump of
+    the scene file the reference ships."""
+    g = O.load_golden("scene_a")
+    hs = lib.HostScene.from_string(scenes.cornell_scene_xml())
+    check_scene_against_dump(hs, g)
+
+
 def mesh_arrays(m):
     A = np.ctypeslib.as_array
     return dict(v=A(m.v, (m.nv, 3)), vn=A(m.vn, (m.nvn, 3)), vt=A(m.vt, (m.nvt, 3)),
