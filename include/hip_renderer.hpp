@@ -8,9 +8,13 @@
 // Differences a caller can see, all forced by where the work runs:
 //   * BeginRender() starts ONE host thread that drives the GPU for the whole frame
 //     (the reference starts hardware_concurrency() tile threads, src/main.cpp:599-606);
-//     pixels appear in the RenderImage when the frame is complete, and
-//     GetNumRenderedPixels() jumps from 0 to width*height at that moment.
-//   * StopRender() waits for the frame in flight (rt_render is one blocking call).
+//     the pixels of the RenderImage are valid when the frame is complete.  While it runs,
+//     GetNumRenderedPixels() / IsRenderDone() follow the GPU's progress (rt_progress): finished
+//     pixels plus, during the first sampling round, the share of its camera paths that have ended.
+//   * StopRender() asks the GPU to stop (rt_cancel) and waits for the worker thread; a stopped
+//     frame leaves LastStatus() == RT_ERR_CANCELLED.
+//   * One GPU context serves one call at a time: TraceRay / TraceShadowRay / TraceRays and the
+//     photon-map calls wait for a frame in flight (they take the same mutex as the worker).
 //   * Rays and hits are plain structs of floats, not cyVector types.
 #ifndef RT_HIP_RENDERER_HPP
 #define RT_HIP_RENDERER_HPP
@@ -21,7 +25,9 @@
 #include <cfloat>
 #include <cstdint>
 #include <cstdio>
+#include <algorithm>
 #include <limits>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -114,8 +120,9 @@ class HipRenderer {
     std::string sceneFile;
     std::atomic<bool> isRendering{false};
     std::thread worker;
+    mutable std::mutex gpu; // one call at a time on the context (rt_cancel and rt_progress excepted)
     rt_render_params params{};
-    int lastStatus = RT_OK;
+    std::atomic<int> lastStatus{RT_OK};
 
     bool Fail(const char *what, const char *msg) const
     {
@@ -177,15 +184,32 @@ public:
     bool RenderFrame()
     {
         if (!ctx || !host) return Fail("RenderFrame", "no scene loaded");
+        std::lock_guard<std::mutex> lock(gpu);
         renderImage.ResetNumRenderedPixels();
         rt_frame_out out{};
         out.rgb = (uint8_t *)renderImage.GetPixels();
         out.z = renderImage.GetZBuffer();
         out.sample_count = (int32_t *)renderImage.GetSampleCount();
         out.object_id = renderImage.GetObjectIds();
-        if ((lastStatus = rt_render(ctx, &params, &out)) != RT_OK) return Fail("rt_render", rt_last_error(ctx));
+        if ((lastStatus = rt_render(ctx, &params, &out)) != RT_OK) return lastStatus == RT_ERR_CANCELLED ? false : Fail("rt_render", rt_last_error(ctx));
+        renderImage.ResetNumRenderedPixels();
         renderImage.IncrementNumRenderPixel(renderImage.GetWidth() * renderImage.GetHeight());
         return true;
+    }
+    // Pixels rendered so far, for a progress bar (the viewer polls RenderImage::GetNumRenderedPixels from its idle
+    // loop, src/viewport.cpp:568-600): call it from the polling thread; it also refreshes the RenderImage's counter.
+    int PollRenderedPixels()
+    {
+        if (!ctx || !isRendering) return renderImage.GetNumRenderedPixels();
+        rt_progress_info pi{};
+        if (rt_progress(ctx, &pi) != RT_OK || !pi.rendering) return renderImage.GetNumRenderedPixels();
+        uint64_t px = pi.pixels_done;
+        if (pi.round == 1 && pi.round_items > 0) px += (pi.pixels_total - pi.pixels_done) * pi.round_items_done / pi.round_items;
+        const int total = renderImage.GetWidth() * renderImage.GetHeight();
+        const int shown = (int)std::min<uint64_t>(px, (uint64_t)(total > 0 ? total - 1 : 0)); // "done" only when the worker says so
+        const int have = renderImage.GetNumRenderedPixels();
+        if (shown > have) renderImage.IncrementNumRenderPixel(shown - have);
+        return renderImage.GetNumRenderedPixels();
     }
     // "Generates one or more rendering threads and begins rendering. Returns immediately." (src/renderer.h:228)
     void BeginRender()
@@ -197,6 +221,15 @@ public:
     // "Stops the current rendering process. It should wait till rendering threads stop." (src/renderer.h:229)
     void StopRender()
     {
+        if (worker.joinable()) {
+            if (isRendering && ctx) rt_cancel(ctx); // no new work for the GPU: the worker returns within milliseconds
+            worker.join();
+        }
+        isRendering = false;
+    }
+    // waits for the frame in flight instead of stopping it
+    void WaitRender()
+    {
         if (worker.joinable()) worker.join();
         isRendering = false;
     }
@@ -206,6 +239,7 @@ public:
     bool TraceRay(Ray const &ray, HitInfo &hInfo) const
     {
         rt_hit h;
+        std::lock_guard<std::mutex> lock(gpu);
         if (!ctx || rt_trace(ctx, ray.p, 1, &h) != RT_OK) return false; // p and dir are contiguous: 6 floats
         if (h.node == -1) return false;
         hInfo.z = h.z; hInfo.node = h.node; hInfo.front = h.front != 0;
@@ -216,6 +250,7 @@ public:
     bool TraceShadowRay(Ray const &ray, float t_max) const
     {
         int32_t occluded = 0;
+        std::lock_guard<std::mutex> lock(gpu);
         if (!ctx || rt_trace_shadow(ctx, ray.p, &t_max, 1, &occluded) != RT_OK) return false;
         return occluded != 0;
     }
@@ -226,6 +261,7 @@ public:
     bool FillPhotonMaps(rt_photon_params const &pp)
     {
         if (!ctx || !host) return Fail("FillPhotonMaps", "no scene loaded");
+        std::lock_guard<std::mutex> lock(gpu);
         if ((lastStatus = rt_photons_fill(ctx, &pp)) != RT_OK) return Fail("rt_photons_fill", rt_last_error(ctx));
         params.photon_flags = pp.flags; // the shader reads what was filled
         return true;
@@ -240,6 +276,7 @@ private:
     bool SetMap(int which, rt_photon const *photons, uint32_t n)
     {
         if (!ctx) return Fail("SetPhotonMap", "no GPU context");
+        std::lock_guard<std::mutex> lock(gpu);
         if ((lastStatus = rt_photons_build(ctx, which, photons, n, 0)) != RT_OK) return Fail("rt_photons_build", rt_last_error(ctx));
         return true;
     }
@@ -247,6 +284,7 @@ private:
     {
         uint32_t n = 0;
         std::vector<rt_photon> out;
+        std::lock_guard<std::mutex> lock(gpu);
         if (!ctx || rt_photons_download(ctx, which, nullptr, &n) != RT_OK || n == 0) return out;
         out.resize(n);
         if (rt_photons_download(ctx, which, out.data(), &n) != RT_OK) out.clear();
@@ -255,7 +293,11 @@ private:
 
 public:
     // many rays at once: one launch instead of one per ray
-    bool TraceRays(const Ray *rays, int n, rt_hit *hits) const { return ctx && rt_trace(ctx, rays[0].p, n, hits) == RT_OK; }
+    bool TraceRays(const Ray *rays, int n, rt_hit *hits) const
+    {
+        std::lock_guard<std::mutex> lock(gpu);
+        return ctx && rt_trace(ctx, rays[0].p, n, hits) == RT_OK;
+    }
 };
 
 static_assert(sizeof(Ray) == 6 * sizeof(float), "Ray must be six packed floats");

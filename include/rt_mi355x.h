@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 3
+#define RT_ABI_VERSION 4
 
 typedef struct rt_ctx rt_ctx;
 
@@ -45,7 +45,8 @@ typedef enum rt_status {
     RT_ERR_HIP = -3,         /* a HIP call failed; see rt_last_error */
     RT_ERR_UNSUPPORTED = -4, /* scene uses a feature outside the supported set */
     RT_ERR_IO = -5,          /* file could not be read or parsed */
-    RT_ERR_STATE = -6        /* call order violated (e.g. render before scene upload) */
+    RT_ERR_STATE = -6,       /* call order violated (e.g. render before scene upload) */
+    RT_ERR_CANCELLED = -7    /* rt_cancel stopped the call; pixels finished in earlier sampling rounds are in the planes, the others are undefined */
 } rt_status;
 
 /* ---- scene description (flattened form of the reference's object model) ---- */
@@ -239,6 +240,23 @@ int rt_camera_set(rt_ctx *ctx, const rt_camera *cam);
 
 /* ---- frame: replaces the thread pool + threadRenderTiles (src/main.cpp:271-385,599-606) ---- */
 int rt_render(rt_ctx *ctx, const rt_render_params *params, rt_frame_out *out);
+
+/* ---- stopping and watching a frame: Renderer::StopRender (src/renderer.h:229, "should wait till rendering threads
+ * stop") and RenderImage::GetNumRenderedPixels / IsRenderDone (src/renderer.h:72-75), which the viewer polls from its
+ * idle loop while the render threads run (src/viewport.cpp:568-600, 625, 766-787).  These two are the only entry
+ * points that may be called from ANOTHER thread while rt_render or rt_photons_fill runs on the context. ---- */
+/* Ask the call in progress to stop: no new work is handed to the GPU (kernels in flight finish the paths they hold:
+ * milliseconds), rt_render / rt_photons_fill return RT_ERR_CANCELLED.  Cleared when the next such call starts. */
+int rt_cancel(rt_ctx *ctx);
+typedef struct rt_progress_info {
+    uint64_t pixels_total;     /* pixels of this context's tile shard */
+    uint64_t pixels_done;      /* of which finished: released by the stop test or at max_spp, planes written */
+    uint64_t round_items;      /* (pixel, sample) camera paths of the sampling round in progress */
+    uint64_t round_items_done; /* of which handed to the GPU and finished, approximately (read while the kernels run) */
+    int32_t round;             /* sampling rounds started so far, 0 before the first */
+    int32_t rendering;         /* 1 while rt_render is inside its rounds */
+} rt_progress_info;
+int rt_progress(rt_ctx *ctx, rt_progress_info *out);
 
 /* ---- batch queries: Renderer::TraceRay / TraceShadowRay (src/main.cpp:115-125)
  * and tracePath (src/main.cpp:160-268) for arrays of rays. rays6 = origin xyz,

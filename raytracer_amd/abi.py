@@ -9,7 +9,7 @@ import ctypes as C
 import numpy as np
 
 RT_OK = 0
-RT_ERR_INVALID, RT_ERR_NO_DEVICE, RT_ERR_HIP, RT_ERR_UNSUPPORTED, RT_ERR_IO, RT_ERR_STATE = -1, -2, -3, -4, -5, -6
+RT_ERR_INVALID, RT_ERR_NO_DEVICE, RT_ERR_HIP, RT_ERR_UNSUPPORTED, RT_ERR_IO, RT_ERR_STATE, RT_ERR_CANCELLED = -1, -2, -3, -4, -5, -6, -7
 RT_NOALLOC_MAX_RAYS = 1 << 24  # rt_trace_brief_noalloc: rays per call
 RT_PRIM_NONE, RT_PRIM_SPHERE, RT_PRIM_PLANE, RT_PRIM_MESH = 0, 1, 2, 3
 RT_LIGHT_AMBIENT, RT_LIGHT_DIRECT, RT_LIGHT_POINT = 0, 1, 2
@@ -110,6 +110,11 @@ class Counters(C.Structure):
                 ("photon_visits", C.c_uint64), ("kernel_ms", C.c_double),
                 ("trace_kernel_ms", C.c_double), ("trace_launches", C.c_uint32), ("trace_pipeline", C.c_uint32),
                 ("phase_cycles", C.c_uint64 * 16)]
+
+
+class ProgressInfo(C.Structure):
+    _fields_ = [("pixels_total", C.c_uint64), ("pixels_done", C.c_uint64), ("round_items", C.c_uint64),
+                ("round_items_done", C.c_uint64), ("round", C.c_int32), ("rendering", C.c_int32)]
 
 
 HIT_DTYPE = np.dtype([("z", "<f4"), ("p", "<f4", 3), ("n", "<f4", 3), ("uvw", "<f4", 3),

@@ -135,11 +135,15 @@ struct WorkQueue {
     unsigned long long *words;
     uint64_t n_items, part; // part: items per queue, a multiple of kChunk
     uint32_t q, tried;      // current part, parts found empty so far
+    uint32_t draws = 0;     // draws of this wave so far
     uint64_t next = 0, end = 0;
     bool exhausted = false;
     uint32_t chunk; // items per draw: large chunks keep a wave on neighbouring pixels (coherent walks), small ones even
                     // out the end of the launch; the host picks it from the items each wave will get (DFrame::chunk)
-    RT_DEV WorkQueue(unsigned long long *w, uint64_t n, uint32_t chunk_items = kChunk) : words(w), n_items(n), chunk(chunk_items)
+    const uint32_t *cancel;              // flag of rt_cancel (pinned host memory)
+    unsigned long long *progress = nullptr; // where to report the queue position for rt_progress (pinned host memory), or null
+    RT_DEV WorkQueue(unsigned long long *w, uint64_t n, uint32_t chunk_items, const uint32_t *cancel_flag, unsigned long long *progress_word = nullptr)
+        : words(w), n_items(n), chunk(chunk_items), cancel(cancel_flag), progress(progress_word)
     {
         const uint64_t chunks = (n + chunk - 1) / chunk;
         part = ((chunks + kQueues - 1) / kQueues) * chunk;
@@ -150,8 +154,13 @@ struct WorkQueue {
     RT_DEV void refill(uint32_t lane)
     {
         while (next >= end && !exhausted) {
+            // the flag lives in host memory (a read costs microseconds): a wave looks at it at every eighth draw
+            if ((draws++ & 7u) == 0u && __hip_atomic_load(cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) { exhausted = true; break; }
             unsigned long long b = 0;
-            if (lane == 0) b = atomicAdd(&words[q * kQueueStride], (unsigned long long)chunk);
+            if (lane == 0) {
+                b = atomicAdd(&words[q * kQueueStride], (unsigned long long)chunk);
+                if (kQueues == 1 && progress) __hip_atomic_store(progress, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); // what had been handed out before this draw
+            }
             b = __shfl(b, 0, 64);
             const uint64_t lo = (uint64_t)q * part, hi = lo + part < n_items ? lo + part : n_items;
             const uint64_t s = lo + b;
@@ -182,7 +191,7 @@ __global__ __launch_bounds__(kBlock, RT_PATHS_MIN_WAVES) void k_paths(DScene S, 
 #ifdef RT_PROFILE_TAIL
     const unsigned long long tail_t0 = wall_clock64();
 #endif
-    WorkQueue wq(queue, n_items, F.chunk); // wave-uniform
+    WorkQueue wq(queue, n_items, F.chunk, S.cancel, S.progress); // wave-uniform
     bool alive = false;
     uint64_t item = 0;
     int pix = 0, k = 0;

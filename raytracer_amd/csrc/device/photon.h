@@ -157,7 +157,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_photon_paths(DScene S, rt_photon_
     const bool direct_only = !caustics_map && (P.flags & (RT_PM_DIRECT | RT_PM_MONTE_CARLO));
     const uint64_t seed = P.seed ^ (caustics_map ? kSeedCausticsMap : kSeedGlobalMap);
 
-    WorkQueue wq(queue, n_paths);
+    WorkQueue wq(queue, n_paths, kChunk, S.cancel);
     bool alive = false, firstHit = true;
     uint32_t item = 0, seq = 0;
     int seg = 0;

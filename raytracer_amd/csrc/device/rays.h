@@ -377,6 +377,8 @@ __global__ __launch_bounds__(kBlock, RT_RAYS_MIN_WAVES) void k_rays(DScene S, IO
         if (idle != 0 && !exhausted && ((uint32_t)__popcll(idle) >= (uint32_t)RT_RAYS_REFILL_MIN_LANES || !__any(w.in_bvh))) {
             if (chunk_next >= chunk_end) {
                 unsigned long long b = 0;
+                // (rt_cancel is not looked at here: a ray launch lasts milliseconds and the host checks between launches;
+                // reading the flag, which lives in host memory, at every draw cost the 1080p frame 13 ms)
                 if (lane == 0) b = atomicAdd(queue, (unsigned long long)ray_chunk);
                 b = __shfl(b, 0, 64);
                 chunk_next = b < n_rays ? (uint32_t)b : n_rays;

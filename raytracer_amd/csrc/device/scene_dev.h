@@ -92,6 +92,9 @@ struct DScene {
     const DTexture *textures;
     int32_t background_texture, environment_texture; // 1 + index, 0 = none
     uint2 *gather_heaps; // [threads of the largest grid][130]: the lanes' heaps of nearest photons
+    // two words of pinned host memory, read and written in place (system scope):
+    const uint32_t *cancel;       // non-zero: hand out no more work (rt_cancel); read by the persistent kernels when they draw from their queues
+    unsigned long long *progress; // items of the running lock-step kernel's queue handed out so far (rt_progress)
 };
 
 // Frame constants (camera + sampling), by value in the kernel arguments.

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(kBlock, RT_WHITTED_MIN_WAVES) void k_whitted(DScene
     const int period = F.halton_period;
     const int pm = F.photon_flags;
 
-    WorkQueue wq(queue, n_items, F.chunk);
+    WorkQueue wq(queue, n_items, F.chunk, S.cancel, S.progress);
     int state = W_IDLE;
     uint64_t item = 0;
     int pix = 0, k = 0, ps_h = 0;

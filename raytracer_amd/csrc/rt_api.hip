@@ -7,6 +7,7 @@
 #include "rt_mi355x.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -97,6 +98,15 @@ struct rt_ctx {
     int active_key[5] = {-1, -1, -1, -1, -1};
     rt_counters counters{};
 
+    // rt_cancel / rt_progress: the only state another thread may touch while a call runs on this context
+    // two words of pinned host memory the GPU reads and writes directly (a copy on another stream would wait behind a
+    // persistent kernel that fills the chip): [0] the flag the kernels read when they draw from their queues,
+    // [1] how far the running lock-step kernel's queue has been handed out
+    unsigned long long *host_words = nullptr;
+    std::atomic<int> cancel_req{0};
+    std::atomic<uint64_t> prog_pixels_total{0}, prog_pixels_done{0}, prog_round_items{0}, prog_round_done{0};
+    std::atomic<int> prog_round{0}, prog_rendering{0}, prog_live_queue{0}; // live_queue: the round's progress is the queue word of the running kernel
+
     int fail(int code, const char *fmt, ...)
     {
         char buf[512];
@@ -114,6 +124,8 @@ struct rt_ctx {
         hipError_t e_ = (expr);                                                                     \
         if (e_ != hipSuccess) return (ctx)->fail(RT_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
+
+static bool cancelled(const rt_ctx *ctx) { return ctx->cancel_req.load(std::memory_order_relaxed) != 0; }
 
 namespace {
 
@@ -173,6 +185,10 @@ int validate_params(rt_ctx *ctx, const rt_render_params *p)
             return ctx->fail(RT_ERR_STATE, "photon_flags ask for the global photon map, which has not been built (rt_photons_fill / rt_photons_build)");
         if ((p->photon_flags & RT_PM_CAUSTICS) && ctx->pmap_n[RT_MAP_CAUSTICS] == 0)
             return ctx->fail(RT_ERR_STATE, "photon_flags ask for the caustics photon map, which has not been built (rt_photons_fill / rt_photons_build)");
+        // maps filled by rt_photons_fill hold the light their flags asked for: reading them under other flags would count
+        // direct light twice or drop it (maps built from the caller's own photons, pmap_flags -1, are taken on trust)
+        if (ctx->pmap_flags != -1 && ctx->pmap_flags != p->photon_flags)
+            return ctx->fail(RT_ERR_STATE, "photon maps were filled with flags 0x%x, the frame asks for 0x%x", ctx->pmap_flags, p->photon_flags);
     }
     if (p->tile_world < 1 || p->tile_rank < 0 || p->tile_rank >= p->tile_world)
         return ctx->fail(RT_ERR_INVALID, "need 0 <= tile_rank < tile_world");
@@ -311,6 +327,8 @@ static int render_wavefront(rt_ctx *ctx, const DFrame &F, const int32_t *act, ui
         HIP_TRY(ctx, hipMemcpyAsync(got, counts, 8, hipMemcpyDeviceToHost, s));
         HIP_TRY(ctx, hipStreamSynchronize(s));
         n_ext = got[0]; n_sh = got[1];
+        ctx->prog_round_done.store(items - n_ext); // paths that have ended
+        if (cancelled(ctx)) break; // the round's kernels hand out no more rays; rt_render reports the cancellation
     }
     HIP_TRY(ctx, hipStreamSynchronize(s));
     for (int i = 0; i < launch; ++i) {
@@ -319,6 +337,27 @@ static int render_wavefront(rt_ctx *ctx, const DFrame &F, const int32_t *act, ui
         *ray_ms += ms;
     }
     *ray_launches += (uint32_t)launch;
+    return RT_OK;
+}
+
+// everything rt_init created, whatever it got to before it failed
+static void destroy_ctx(rt_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
+    if (ctx->host_words) (void)hipHostFree(ctx->host_words);
+    for (hipEvent_t ev : ctx->ray_ev) if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : {ctx->ev0, ctx->ev1, ctx->evk0, ctx->evk1}) if (ev) (void)hipEventDestroy(ev);
+    delete ctx;
+}
+
+// start of a call that rt_cancel can stop: the flag of the previous call is cleared, on the host and on the device
+static int begin_cancellable(rt_ctx *ctx)
+{
+    ctx->cancel_req.store(0);
+    __atomic_store_n(&ctx->host_words[0], 0ull, __ATOMIC_RELEASE); // nothing of this context runs on the GPU between calls
+    __atomic_store_n(&ctx->host_words[1], 0ull, __ATOMIC_RELEASE);
     return RT_OK;
 }
 
@@ -342,7 +381,7 @@ int rt_init(int device, rt_ctx **out)
     ctx->device = device;
     auto bail = [&](const char *what, hipError_t err) {
         g_init_error = std::string(what) + ": " + hipGetErrorString(err);
-        delete ctx;
+        destroy_ctx(ctx);
         return RT_ERR_HIP;
     };
     if ((e = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", e);
@@ -384,18 +423,32 @@ int rt_init(int device, rt_ctx **out)
     if (const char *e7 = getenv("RT_ORDER")) ctx->order_pixels = atoi(e7) != 0 ? 1 : 0;
     if (const char *e2 = getenv("RT_LDS_LEVELS")) ctx->lds_levels_max = std::max(1, std::min(64, atoi(e2))); // tuning knob
     if ((e = ctx->d_queue.reserve(kQueueBytes)) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipHostMalloc((void **)&ctx->host_words, 64, hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess) return bail("hipHostMalloc", e);
+    memset(ctx->host_words, 0, 64);
     *out = ctx;
     return RT_OK;
 }
 
-void rt_shutdown(rt_ctx *ctx)
+void rt_shutdown(rt_ctx *ctx) { destroy_ctx(ctx); }
+
+int rt_cancel(rt_ctx *ctx)
 {
-    if (!ctx) return;
-    (void)hipSetDevice(ctx->device);
-    if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
-    for (hipEvent_t ev : ctx->ray_ev) if (ev) (void)hipEventDestroy(ev);
-    for (hipEvent_t ev : {ctx->ev0, ctx->ev1, ctx->evk0, ctx->evk1}) if (ev) (void)hipEventDestroy(ev);
-    delete ctx;
+    if (!ctx) return RT_ERR_INVALID;
+    // no HIP call and no error text here: both belong to the thread inside the call being cancelled
+    ctx->cancel_req.store(1);
+    __atomic_store_n(&ctx->host_words[0], 1ull, __ATOMIC_RELEASE);
+    return RT_OK;
+}
+
+int rt_progress(rt_ctx *ctx, rt_progress_info *out)
+{
+    if (!ctx || !out) return RT_ERR_INVALID;
+    out->pixels_total = ctx->prog_pixels_total.load(); out->pixels_done = ctx->prog_pixels_done.load();
+    out->round_items = ctx->prog_round_items.load(); out->round_items_done = ctx->prog_round_done.load();
+    out->round = ctx->prog_round.load(); out->rendering = ctx->prog_rendering.load();
+    if (out->rendering && ctx->prog_live_queue.load()) // a lock-step kernel is running: it reports its queue position
+        out->round_items_done = std::min<uint64_t>(__atomic_load_n(&ctx->host_words[1], __ATOMIC_ACQUIRE), out->round_items);
+    return RT_OK;
 }
 
 int rt_set_counting(rt_ctx *ctx, int on)
@@ -663,6 +716,8 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc)
     HIP_TRY(ctx, hipMemcpy(ctx->d_tnodes.p, tnodes.data(), sizeof(TNode) * nn, hipMemcpyHostToDevice));
     S.tnodes = ctx->d_tnodes.as<TNode>();
     S.bvh_pool = d_bvh_pool; S.tri_pool = d_tri_pool; S.bvh4_pool = d_bvh4_pool;
+    S.cancel = (const uint32_t *)&ctx->host_words[0];
+    S.progress = &ctx->host_words[1];
     HIP_TRY(ctx, ctx->d_meshes.reserve(sizeof(DMesh) * std::max<size_t>(1, dmeshes.size())));
     if (!dmeshes.empty()) HIP_TRY(ctx, hipMemcpy(ctx->d_meshes.p, dmeshes.data(), sizeof(DMesh) * dmeshes.size(), hipMemcpyHostToDevice));
     HIP_TRY(ctx, ctx->d_materials.reserve(sizeof(rt_material) * std::max<uint32_t>(1, sc->n_materials)));
@@ -774,6 +829,11 @@ int rt_render(rt_ctx *ctx, const rt_render_params *prm, rt_frame_out *out)
     double trace_ms = 0.0;
     uint32_t launches = 0;
     uint64_t wf_paths = 0; // camera paths of the wavefront pipeline (its kernels count rays only)
+    if (int rc = begin_cancellable(ctx)) return rc;
+    ctx->prog_pixels_total.store(n0); ctx->prog_pixels_done.store(0); ctx->prog_round.store(0);
+    ctx->prog_round_items.store(0); ctx->prog_round_done.store(0); ctx->prog_live_queue.store(0);
+    ctx->prog_rendering.store(1);
+    struct Done { rt_ctx *c; ~Done() { c->prog_rendering.store(0); c->prog_live_queue.store(0); } } done_guard{ctx};
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, s));
 
     // Expensive pixels first (path frames): keys from one camera ray per pixel, then a stable descending radix sort.
@@ -814,6 +874,7 @@ int rt_render(rt_ctx *ctx, const rt_render_params *prm, rt_frame_out *out)
     int cur = 0, k0 = 0;
     while (n_active > 0 && k0 < prm->max_spp) {
         const int nk = k0 == 0 ? prm->min_spp : std::min(16, prm->max_spp - k0);
+        ctx->prog_round.fetch_add(1);
         const uint32_t chunk_px = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_active, kMaxItems / (uint64_t)nk));
         HIP_TRY(ctx, ctx->d_sbuf.reserve((size_t)chunk_px * nk * sizeof(float4)));
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_next_count.p, 0, sizeof(uint32_t), s));
@@ -821,6 +882,9 @@ int rt_render(rt_ctx *ctx, const rt_render_params *prm, rt_frame_out *out)
             const uint32_t cnt = std::min(chunk_px, n_active - first);
             const uint64_t items = (uint64_t)cnt * nk;
             const int32_t *act = (k0 == 0 ? first_list : ctx->d_active[cur].as<int32_t>()) + first;
+            ctx->prog_round_done.store(0); ctx->prog_round_items.store(items);
+            __atomic_store_n(&ctx->host_words[1], 0ull, __ATOMIC_RELEASE);
+            ctx->prog_live_queue.store(wavefront || prm->max_bounces <= 0 ? 0 : 1);
             HIP_TRY(ctx, hipEventRecord(ctx->evk0, s));
             if (prm->mode == RT_MODE_WHITTED) {
                 const void *fn = whitted_kernel(ctx->counting, ctx->ray_levels);
@@ -906,6 +970,9 @@ int rt_render(rt_ctx *ctx, const rt_render_params *prm, rt_frame_out *out)
         uint32_t next = 0;
         HIP_TRY(ctx, hipMemcpyAsync(&next, ctx->d_next_count.p, sizeof next, hipMemcpyDeviceToHost, s));
         HIP_TRY(ctx, hipStreamSynchronize(s));
+        ctx->prog_live_queue.store(0);
+        if (cancelled(ctx)) return ctx->fail(RT_ERR_CANCELLED, "cancelled by rt_cancel after %d samples per pixel", k0);
+        ctx->prog_pixels_done.store(n0 - next);
         n_active = next;
         cur ^= 1;
         k0 += nk;
@@ -1249,7 +1316,8 @@ int rt_photons_emit(rt_ctx *ctx, const rt_photon_params *pp, int which, uint64_t
     }
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters.p, 0, sizeof(DCounters), s));
     HIP_TRY(ctx, hipEventRecord(ctx->evk0, s));
-    const uint64_t kMaxChunk = 1ull << 24; // keeps the 32-bit offsets of a launch below 2^24 * max_segments
+    // photon offsets inside a launch are 32-bit: a launch's paths times the photons a path can store must stay below 2^32
+    const uint64_t kMaxChunk = std::min<uint64_t>(1ull << 24, 0xFFFFFFFFull / (uint64_t)pp->max_segments);
     uint64_t stored = 0;
     for (uint64_t first = 0; first < path_count; first += kMaxChunk) {
         const uint32_t n = (uint32_t)std::min<uint64_t>(kMaxChunk, path_count - first);
@@ -1315,6 +1383,7 @@ int rt_photons_fill(rt_ctx *ctx, const rt_photon_params *pp)
     if (!ctx->have_scene) return ctx->fail(RT_ERR_STATE, "no scene uploaded");
     if (int rc = validate_photon_params(ctx, pp, RT_MAP_GLOBAL)) return rc;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (int rc = begin_cancellable(ctx)) return rc;
     double emit_ms = 0.0;
     uint64_t rays = 0, paths_total = 0;
     for (int which = 0; which < 2; ++which) {
@@ -1328,6 +1397,7 @@ int rt_photons_fill(rt_ctx *ctx, const rt_photon_params *pp)
         uint64_t stored = 0, path = 0, round = 1u << 16;
         int barren = 0;
         while (stored < cap) {
+            if (cancelled(ctx)) return ctx->fail(RT_ERR_CANCELLED, "cancelled by rt_cancel while filling the photon maps");
             uint64_t got = 0;
             if (int rc = rt_photons_emit(ctx, pp, which, path, round, raw.as<rt_photon>() + stored, (uint32_t)(cap - stored), &got, 1)) return rc;
             emit_ms += ctx->counters.kernel_ms; rays += ctx->counters.closest_rays; paths_total += round;

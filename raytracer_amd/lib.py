@@ -21,7 +21,7 @@ SYMBOLS = (
     "rt_trace", "rt_trace_shadow", "rt_trace_brief", "rt_trace_brief_noalloc", "rt_trace_paths", "rt_get_counters", "rt_set_counting",
     "rt_scene_load_xml", "rt_scene_from_xml_string", "rt_scene_host_desc", "rt_scene_host_camera",
     "rt_scene_host_free", "rt_scene_host_set_mesh", "rt_bvh_build", "rt_free",
-    "rt_photons_emit", "rt_photons_build", "rt_photons_fill", "rt_photons_download", "rt_photons_irradiance",
+    "rt_cancel", "rt_progress", "rt_photons_emit", "rt_photons_build", "rt_photons_fill", "rt_photons_download", "rt_photons_irradiance",
 )
 
 _lib = None
@@ -50,6 +50,8 @@ def load():
     L.rt_scene_upload.argtypes = [vp, C.POINTER(abi.SceneDesc)]
     L.rt_camera_set.argtypes = [vp, C.POINTER(abi.Camera)]
     L.rt_render.argtypes = [vp, C.POINTER(abi.RenderParams), C.POINTER(abi.FrameOut)]
+    L.rt_cancel.argtypes = [vp]
+    L.rt_progress.argtypes = [vp, C.POINTER(abi.ProgressInfo)]
     L.rt_trace.argtypes = [vp, abi.f32p, C.c_int, C.POINTER(abi.Hit)]
     L.rt_trace_shadow.argtypes = [vp, abi.f32p, abi.f32p, C.c_int, abi.i32p]
     L.rt_trace_brief.argtypes = [vp, abi.f32p, abi.f32p, C.c_int, C.POINTER(abi.HitBrief)]
@@ -197,6 +199,17 @@ class Context:
         """Render into device memory; arguments are device addresses (0 = plane not wanted)."""
         out = abi.FrameOut(rgb or None, z or None, sample_count or None, object_id or None, linear or None, 1)
         self._check(self._L.rt_render(self._h, C.byref(params), C.byref(out)))
+
+    def cancel(self):
+        """rt_cancel: callable from another thread while render() runs."""
+        return self._L.rt_cancel(self._h)
+
+    def progress(self):
+        p = abi.ProgressInfo()
+        rc = self._L.rt_progress(self._h, C.byref(p))
+        if rc:
+            raise RtError(rc, "rt_progress")
+        return p
 
     def counters(self):
         c = abi.Counters()

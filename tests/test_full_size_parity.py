@@ -205,3 +205,75 @@ def test_whitted_photon_image_with_this_context(ctx):
                                        mode=abi.RT_MODE_WHITTED, photon_flags=flags, gather_radius=3.0))
     assert np.array_equal(fr.object_id, g["object_id"]) and np.array_equal(bits(fr.z), bits(g["z"]))
     assert O.psnr(fr.rgb, g["rgb"]) >= PSNR_MIN
+
+
+# ---------------------------------------------------------------- stopping and watching a frame
+def _cancel_midway(ctx, prm, w, h):
+    """Render in a worker thread (the binding releases the GIL inside rt_render), poll rt_progress from this thread,
+    call rt_cancel once the first camera paths have ended.  Returns (status of the cancelled call, progress samples)."""
+    import threading
+    import time
+    res = {}
+
+    def run():
+        try:
+            ctx.render(prm)
+            res["rc"] = 0
+        except lib.RtError as e:
+            res["rc"] = e.code
+
+    th = threading.Thread(target=run)
+    th.start()
+    seen = []
+    t0 = time.time()
+    while th.is_alive() and time.time() - t0 < 60:
+        p = ctx.progress()
+        seen.append((p.round, p.round_items, p.round_items_done, p.pixels_done, p.pixels_total, p.rendering))
+        if p.rendering and p.round >= 1 and p.round_items_done > 0:
+            assert ctx.cancel() == 0
+            break
+        time.sleep(0.0005)
+    th.join(120)
+    assert not th.is_alive()
+    return res["rc"], seen
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene", ["mesh_wavefront", "cornell_lockstep"])
+def test_cancel_and_progress(scene):
+    """rt_cancel from another thread stops a frame (RT_ERR_CANCELLED) long before its end, rt_progress moves while the
+    frame runs, and the next frame on the context is bit-identical to one rendered before the cancellation."""
+    c = lib.Context(0)
+    try:
+        if scene == "mesh_wavefront":
+            hs, _ = scene_c()
+            w, h = 1920, 1080
+            prm = abi.default_params(seed=5, min_spp=48, max_spp=192, delta_max=1e-5)
+        else:
+            hs = lib.HostScene.from_string(scenes.cornell_scene_xml())
+            w, h = 1280, 720
+            prm = abi.default_params(seed=5, min_spp=256, max_spp=256)
+        c.upload(hs.desc)
+        c.set_camera(hs.camera, w, h)
+        small = abi.default_params(seed=9, min_spp=2, max_spp=2)
+        before = c.render(small)
+        import time
+        t0 = time.time()
+        rc, seen = _cancel_midway(c, prm, w, h)
+        dt = time.time() - t0
+        assert rc == abi.RT_ERR_CANCELLED, (rc, seen[-3:])
+        assert any(s[2] > 0 and s[2] < s[1] for s in seen), "progress was seen moving inside a sampling round"
+        assert seen[-1][4] == w * h
+        p = c.progress()
+        assert not p.rendering
+        t0 = time.time()
+        after = c.render(small)
+        for k in ("rgb", "z", "sample_count", "object_id"):
+            assert np.array_equal(getattr(before, k), getattr(after, k)), k
+        assert np.array_equal(bits(before.linear), bits(after.linear))
+        full_t0 = time.time()
+        c.render(prm)  # the same frame, not cancelled, for the time it takes
+        full = time.time() - full_t0
+        assert dt < 0.6 * full + 0.05, f"cancelled call took {dt:.3f} s, the whole frame takes {full:.3f} s"
+    finally:
+        c.close()

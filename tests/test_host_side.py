@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(lib.SYMBOLS)
     for name in declared:
         assert hasattr(L, name), name
-    assert L.rt_abi_version() == 3
+    assert L.rt_abi_version() == 4
 
 
 def test_struct_sizes_match_header(tmp_path):
@@ -35,7 +35,7 @@ def test_struct_sizes_match_header(tmp_path):
     import subprocess
     pairs = {"rt_node": abi.Node, "rt_bvh_node": abi.BvhNode, "rt_material": abi.Material, "rt_light": abi.Light,
              "rt_hit": abi.Hit, "rt_hit_brief": abi.HitBrief, "rt_render_params": abi.RenderParams, "rt_camera": abi.Camera,
-             "rt_frame_out": abi.FrameOut, "rt_counters": abi.Counters, "rt_photon_params": abi.PhotonParams,
+             "rt_frame_out": abi.FrameOut, "rt_counters": abi.Counters, "rt_photon_params": abi.PhotonParams, "rt_progress_info": abi.ProgressInfo,
              "rt_scene_desc": abi.SceneDesc}
     src = "#include <stdio.h>\n#include \"rt_mi355x.h\"\nint main(void){\n"
     src += "".join(f'printf("{n} %zu\\n", sizeof({n}));\n' for n in pairs)
