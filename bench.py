@@ -224,7 +224,7 @@ def main():
     if args.tile_size:
         prm.tile_size = args.tile_size
     fb = FrameBuffers(w, h, dev)
-    gather = FrameGather(w, h, prm.tile_size, rank, world, dev)
+    gather = FrameGather(w, h, prm.tile_size, rank, world, dev, ctx=ctx)
     filler = PhotonFill(ctx, rank, world, dev) if pp else None
     host_rgb = torch.empty((w * h, 3), dtype=torch.uint8).pin_memory()
     photon_stats = {}
@@ -264,6 +264,16 @@ def main():
     fence()
     dt = time.perf_counter() - t0
 
+    exchange_ms = None
+    if args.shard and tile_world > 1:
+        # what the frame exchange costs a rank beside the all-gather itself: packing its records and unpacking everybody's
+        g = FrameGather(w, h, prm.tile_size, tile_rank, tile_world, dev, ctx=ctx)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(20):
+            g.pack(fb)
+            g.unpack(fb)
+        exchange_ms = (time.perf_counter() - t1) / 20 * 1e3
     c = ctx.counters()
     photon_rays = photon_stats.get("rays", 0)
     stats = torch.tensor([c.closest_rays, c.shadow_rays, c.camera_paths, counted.box_tests, counted.tri_tests,
@@ -320,6 +330,8 @@ def main():
                               "gather_ms": photon_stats.get("gather_ms"), "build_ms": photon_stats.get("build_ms"),
                               "gathers_per_frame": int(stats[5].item()), "node_visits_per_frame": int(stats[6].item()),
                               "gathers_per_s": float(stats[5].item()) * args.steps / dt}
+        if exchange_ms is not None:
+            out["frame_exchange_pack_unpack_ms"] = exchange_ms
         if any(c.phase_cycles):
             out["phase_cycles"] = list(c.phase_cycles)
         if world == 1 and not args.no_cpu_baseline:

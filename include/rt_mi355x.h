@@ -241,6 +241,15 @@ int rt_camera_set(rt_ctx *ctx, const rt_camera *cam);
 /* ---- frame: replaces the thread pool + threadRenderTiles (src/main.cpp:271-385,599-606) ---- */
 int rt_render(rt_ctx *ctx, const rt_render_params *params, rt_frame_out *out);
 
+/* ---- frame exchange between GPUs (no counterpart in the reference, which is one process): a rank's finished pixels
+ * as one array of 16-byte records (rgb, z, sample count, object id) in tile order, ready for ONE all-gather, and the
+ * way back.  Every tile takes tile_size^2 records, so all ranks' arrays have rt_frame_records() entries.  `planes`
+ * are DEVICE pointers (rgb, z, sample_count and object_id all non-null); both calls return when the GPU is done. ---- */
+uint32_t rt_frame_records(int width, int height, int tile_size, int world);
+int rt_frame_pack(rt_ctx *ctx, const rt_frame_out *planes, int tile_size, int rank, int world, void *packed);
+/* packed_all: the world ranks' arrays in rank order (what the all-gather delivers); skip_rank's pixels are left alone */
+int rt_frame_unpack(rt_ctx *ctx, const void *packed_all, int tile_size, int skip_rank, int world, const rt_frame_out *planes);
+
 /* ---- stopping and watching a frame: Renderer::StopRender (src/renderer.h:229, "should wait till rendering threads
  * stop") and RenderImage::GetNumRenderedPixels / IsRenderDone (src/renderer.h:72-75), which the viewer polls from its
  * idle loop while the render threads run (src/viewport.cpp:568-600, 625, 766-787).  These two are the only entry

@@ -396,6 +396,53 @@ __global__ __launch_bounds__(kBlock) void k_resolve(DFrame F, const int32_t *__r
     if (out.sample_count) out.sample_count[pix] = s.n;
 }
 
+// ---- frame exchange between GPUs ----
+// A rank's pixels travel as one 16-byte record each: (r | g << 8 | b << 16, z, sample count, object id).  Record s of
+// rank r belongs to tile r + (s / ts^2) * world, pixel (s % ts, s % ts^2 / ts) of it: every tile takes ts^2 records,
+// the ones of a ragged tile's missing pixels are zero, so the place of a pixel follows from arithmetic alone.
+RT_DEV bool exchange_pixel(uint32_t s, int rank, int world, int ts, int width, int height, int &pix)
+{
+    const int tx = (width + ts - 1) / ts, ty = (height + ts - 1) / ts;
+    const int per = ts * ts;
+    const int t = rank + (int)(s / (uint32_t)per) * world;
+    if (t >= tx * ty) return false;
+    const int o = (int)(s % (uint32_t)per);
+    const int x = (t % tx) * ts + o % ts, y = (t / tx) * ts + o / ts;
+    if (x >= width || y >= height) return false;
+    pix = y * width + x;
+    return true;
+}
+__global__ __launch_bounds__(kBlock) void k_frame_pack(FramePlanes in, int width, int height, int ts, int rank, int world,
+                                                       uint32_t n_records, uint4 *__restrict__ packed)
+{
+    const uint32_t s = blockIdx.x * kBlock + threadIdx.x;
+    if (s >= n_records) return;
+    int pix;
+    uint4 rec = make_uint4(0, 0, 0, 0);
+    if (exchange_pixel(s, rank, world, ts, width, height, pix)) {
+        rec.x = (uint32_t)in.rgb[pix * 3] | ((uint32_t)in.rgb[pix * 3 + 1] << 8) | ((uint32_t)in.rgb[pix * 3 + 2] << 16);
+        rec.y = __float_as_uint(in.z[pix]);
+        rec.z = (uint32_t)in.sample_count[pix];
+        rec.w = (uint32_t)in.object_id[pix];
+    }
+    packed[s] = rec;
+}
+// packed_all = the ranks' record arrays one after the other; the pixels of `skip_rank` (this rank's own) stay as they are
+__global__ __launch_bounds__(kBlock) void k_frame_unpack(const uint4 *__restrict__ packed_all, int width, int height, int ts,
+                                                         int skip_rank, int world, uint32_t n_records, FramePlanes out)
+{
+    const uint32_t s = blockIdx.x * kBlock + threadIdx.x;
+    const int rank = (int)blockIdx.y;
+    if (s >= n_records || rank == skip_rank) return;
+    int pix;
+    if (!exchange_pixel(s, rank, world, ts, width, height, pix)) return;
+    const uint4 rec = packed_all[(size_t)rank * n_records + s];
+    out.rgb[pix * 3] = (uint8_t)rec.x; out.rgb[pix * 3 + 1] = (uint8_t)(rec.x >> 8); out.rgb[pix * 3 + 2] = (uint8_t)(rec.x >> 16);
+    out.z[pix] = __uint_as_float(rec.y);
+    out.sample_count[pix] = (int32_t)rec.z;
+    out.object_id[pix] = (int32_t)rec.w;
+}
+
 // ---- batch queries: grid-stride loops, the grid is bounded by the host so that the
 // per-thread stack overflow area covers every thread ----
 __global__ __launch_bounds__(kBlock) void k_trace(DScene S, const float *__restrict__ rays6, int n, rt_hit *__restrict__ out)

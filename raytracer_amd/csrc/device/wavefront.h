@@ -127,6 +127,40 @@ __global__ __launch_bounds__(kBlock) void k_planes(DScene S, DFrame F, const flo
     }
 }
 
+// The last of a round's paths, to their ends in one launch.  After a few bounces a handful of paths is left (glass,
+// mirrors), and a bounce of the pipeline - a ray launch for a thousand rays, a shading launch, the host reading the
+// counts - takes 0.2 ms however few they are: forty more of those are 8 to 10 ms, a third of a frame's time on one
+// eighth of the image.  Here a lane takes one live path and runs tracePath's loop on it (path_step, the lock-step
+// kernel's own code, binary BVH walk) until it ends.
+template <bool COUNT, int LEVELS>
+__global__ __launch_bounds__(kBlock) void k_wf_finish(DScene S, DFrame F, int k0, int nk, WfState P,
+                                                      const uint32_t *__restrict__ queue_in, uint32_t n_in, DCounters *ctr)
+{
+    extern __shared__ uint32_t lds[];
+    const LaneStack st = lane_stack(lds, S);
+    PathTally pt;
+    Tally<COUNT> tl;
+    for (uint32_t e = blockIdx.x * kBlock + threadIdx.x; e < n_in; e += gridDim.x * kBlock) {
+        const uint32_t slot = queue_in[e];
+        const float4 ro = P.ray_o[slot], rd = P.ray_d[slot], t = P.thr[slot], a = P.acc[slot];
+        const uint2 rs = P.rng[slot];
+        const int k = k0 + (int)(slot % (uint32_t)nk);
+        const uint32_t bits = __float_as_uint(rd.w);
+        PathState ps;
+        ps.ray = Ray{mk(ro.x, ro.y, ro.z), mk(rd.x, rd.y, rd.z)};
+        ps.throughput = mk(t.x, t.y, t.z);
+        ps.result = mk(a.x, a.y, a.z);
+        ps.rng.state = ((uint64_t)rs.y << 32) | rs.x;
+        ps.rng.inc = (((uint64_t)k + 1) << 1u) | 1u;
+        ps.lastProb = ro.w;
+        ps.lastLobe = (int)(bits >> 16);
+        ps.bounce = (int)(bits & 0xFFFFu);
+        while (path_step<COUNT, LEVELS, true>(S, F, ps, st, pt, tl, nullptr, nullptr)) {}
+        P.acc[slot] = make_float4(ps.result.x, ps.result.y, ps.result.z, a.w);
+    }
+    flush_counters<COUNT>(ctr, pt, tl, 0);
+}
+
 constexpr uint32_t kShadeRounds = 8;                      // paths per lane and list reservation
 constexpr uint32_t kShadeChunk = kShadeRounds * kBlock;   // paths per workgroup and list reservation
 

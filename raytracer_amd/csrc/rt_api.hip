@@ -80,6 +80,7 @@ struct rt_ctx {
     DeviceBuf d_wf_state, d_wf_queue[2], d_wf_sh_queue, d_wf_counts;
     static constexpr int kMaxRayLaunches = 96;
     hipEvent_t ray_ev[2 * kMaxRayLaunches] = {};
+    uint32_t finish_below = 0; // RT_FINISH_BELOW: paths left in a round at which the wavefront pipeline hands over to k_wf_finish (default: 512 per CU; measured 8 k / 32 k / 128 k / 512 k: 101.3 / 99.8 / 98.3 / 99.2 ms per 1080p frame, 20.3 / 19.3 / 17.9 / 19.1 ms on an eighth of it)
     int pipeline = -1; // RT_PIPELINE: 0 = lock-step path kernel (k_paths), 1 = wavefront; -1: chosen per scene (wavefront when it has meshes)
     size_t ovf_threads = 0;
     int lds_levels_max = 13;
@@ -293,11 +294,12 @@ static int render_wavefront(rt_ctx *ctx, const DFrame &F, const int32_t *act, ui
     unsigned long long *a_queue = ctx->d_queue.as<unsigned long long>();
     uint32_t *counts = ctx->d_wf_counts.as<uint32_t>();
 
-    uint32_t n_ext = items, n_sh = 0;
+    uint32_t n_ext = items, n_sh = 0, held_ext = 0;
+    bool finishing = false;
     int cur = 0, launch = 0;
     const uint32_t *queue_in = nullptr; // the camera rays: slot e
-    for (int bounce = 0; n_ext + n_sh > 0; ++bounce) {
-        {   // extension rays of this bounce, shadow rays of the previous one
+    for (int bounce = 0; n_ext + n_sh > 0 || finishing; ++bounce) {
+        if (n_ext + n_sh > 0) { // extension rays of this bounce, shadow rays of the previous one
             const uint64_t n_rays = (uint64_t)n_ext + n_sh;
             const dim3 grid((unsigned)std::min<uint64_t>((n_rays + kBlock - 1) / kBlock, (uint64_t)ctx->n_cu * per_cu));
             WfIO a_io{P, queue_in, ctx->d_wf_sh_queue.as<uint32_t>(), n_ext};
@@ -312,7 +314,20 @@ static int render_wavefront(rt_ctx *ctx, const DFrame &F, const int32_t *act, ui
             HIP_TRY(ctx, hipLaunchKernel(fn, grid, dim3(kBlock), targs, lds, s));
             if (timed) { HIP_TRY(ctx, hipEventRecord(ctx->ray_ev[2 * launch + 1], s)); ++launch; }
         }
+        if (finishing) n_ext = held_ext;
         if (n_ext == 0) break; // those were the last shadow rays
+        if (finishing) { // the shadow rays of the last shaded bounce are in; the remaining paths run to their ends in one launch
+            const void *ff = ctx->counting ? (ctx->ray_levels <= 1 ? (const void *)k_wf_finish<true, 1> : ctx->ray_levels == 2 ? (const void *)k_wf_finish<true, 2> : (const void *)k_wf_finish<true, 5>)
+                                           : (ctx->ray_levels <= 1 ? (const void *)k_wf_finish<false, 1> : ctx->ray_levels == 2 ? (const void *)k_wf_finish<false, 2> : (const void *)k_wf_finish<false, 5>);
+            const dim3 grid((unsigned)std::min<uint64_t>(((uint64_t)n_ext + kBlock - 1) / kBlock, ctx->ovf_threads / kBlock));
+            DFrame f_frame = F;
+            int f_k0 = k0, f_nk = nk;
+            uint32_t f_n = n_ext;
+            void *fargs[] = {&a_scene, &f_frame, &f_k0, &f_nk, &P, &queue_in, &f_n, &a_ctr};
+            HIP_TRY(ctx, hipLaunchKernel(ff, grid, dim3(kBlock), fargs, lds, s));
+            ctx->prog_round_done.store(items);
+            break;
+        }
         HIP_TRY(ctx, hipMemsetAsync(counts, 0, 8, s));
         {
             const dim3 grid((unsigned)std::min<uint64_t>(((uint64_t)n_ext + kShadeChunk - 1) / kShadeChunk, (uint64_t)ctx->n_cu * 16));
@@ -328,6 +343,8 @@ static int render_wavefront(rt_ctx *ctx, const DFrame &F, const int32_t *act, ui
         HIP_TRY(ctx, hipStreamSynchronize(s));
         n_ext = got[0]; n_sh = got[1];
         ctx->prog_round_done.store(items - n_ext); // paths that have ended
+        // few paths left: their shadow rays next (a ray launch without extension rays), then k_wf_finish
+        if (n_ext > 0 && n_ext <= ctx->finish_below && bounce + 1 < F.max_bounces) { finishing = true; held_ext = n_ext; n_ext = 0; }
         if (cancelled(ctx)) break; // the round's kernels hand out no more rays; rt_render reports the cancellation
     }
     HIP_TRY(ctx, hipStreamSynchronize(s));
@@ -404,6 +421,8 @@ int rt_init(int device, rt_ctx **out)
                           (const void *)k_whitted<true, 1>, (const void *)k_whitted<true, 2>, (const void *)k_whitted<true, 5>,
                           (const void *)k_probe<1>, (const void *)k_probe<2>, (const void *)k_probe<5>,
                           (const void *)k_planes<1>, (const void *)k_planes<2>, (const void *)k_planes<5>,
+                          (const void *)k_wf_finish<false, 1>, (const void *)k_wf_finish<false, 2>, (const void *)k_wf_finish<false, 5>,
+                          (const void *)k_wf_finish<true, 1>, (const void *)k_wf_finish<true, 2>, (const void *)k_wf_finish<true, 5>,
                           (const void *)k_order_keys<1>, (const void *)k_order_keys<2>, (const void *)k_order_keys<5>,
                           (const void *)k_trace, (const void *)k_trace_shadow, (const void *)k_trace_paths})
         (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -416,6 +435,8 @@ int rt_init(int device, rt_ctx **out)
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
     ctx->n_cu = prop.multiProcessorCount;
+    ctx->finish_below = (uint32_t)ctx->n_cu * 512u;
+    if (const char *e9 = getenv("RT_FINISH_BELOW")) ctx->finish_below = (uint32_t)std::max(0, atoi(e9));
     if (const char *e3 = getenv("RT_PIPELINE")) ctx->pipeline = strcmp(e3, "wave") == 0 ? 1 : strcmp(e3, "mega") == 0 ? 0 : -1;
     for (hipEvent_t &ev : ctx->ray_ev)
         if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
@@ -842,7 +863,8 @@ int rt_render(rt_ctx *ctx, const rt_render_params *prm, rt_frame_out *out)
     // (0.6 ms); on the 1/8 shard of an 8-GPU run the launch is 1.0 ms shorter (22.4 -> 21.4 ms), so it is on for shards.
     const int32_t *first_list = ctx->d_active_all.as<int32_t>();
     const bool order = ctx->order_pixels < 0 ? prm->tile_world > 1 : ctx->order_pixels != 0;
-    if (order && prm->mode == RT_MODE_PATH && prm->max_bounces > 0 && n0 > 1) {
+    const bool wavefront_frame = prm->mode == RT_MODE_PATH && prm->max_bounces > 0 && (ctx->pipeline == 1 || (ctx->pipeline < 0 && ctx->have_meshes));
+    if (order && prm->mode == RT_MODE_PATH && prm->max_bounces > 0 && n0 > 1 && !wavefront_frame) { // (the wavefront pipeline has all paths of a round in flight at once: nothing to order)
         HIP_TRY(ctx, ctx->d_active_sorted.reserve(sizeof(int32_t) * n0));
         for (auto &b : ctx->d_keys) HIP_TRY(ctx, b.reserve(sizeof(uint32_t) * n0));
         const void *fn = ctx->ray_levels <= 1 ? (const void *)k_order_keys<1> : ctx->ray_levels == 2 ? (const void *)k_order_keys<2> : (const void *)k_order_keys<5>;
@@ -1007,6 +1029,54 @@ int rt_render(rt_ctx *ctx, const rt_render_params *prm, rt_frame_out *out)
     c.gathers = dc.gathers; c.photon_visits = dc.photon_visits;
     for (int i = 0; i < 16; ++i) c.phase_cycles[i] = dc.phase[i];
     c.kernel_ms = ms; c.trace_kernel_ms = trace_ms; c.trace_launches = launches; c.trace_pipeline = wavefront ? 1u : 0u;
+    return RT_OK;
+}
+
+// ---- frame exchange between GPUs ----
+uint32_t rt_frame_records(int width, int height, int tile_size, int world)
+{
+    if (width < 1 || height < 1 || tile_size < 1 || world < 1) return 0;
+    const uint64_t tiles = (uint64_t)((width + tile_size - 1) / tile_size) * ((height + tile_size - 1) / tile_size);
+    return (uint32_t)((tiles + world - 1) / world * (uint64_t)tile_size * tile_size);
+}
+
+static int exchange_args(rt_ctx *ctx, const rt_frame_out *pl, const void *packed, int tile_size, int rank, int world, FramePlanes &P)
+{
+    if (!ctx->have_camera) return ctx->fail(RT_ERR_STATE, "rt_camera_set first: the frame exchange needs the image size");
+    if (!pl || !packed || !pl->rgb || !pl->z || !pl->sample_count || !pl->object_id || !pl->device_memory)
+        return ctx->fail(RT_ERR_INVALID, "the frame exchange needs device pointers for rgb, z, sample_count and object_id");
+    if (tile_size < 1 || world < 1 || rank < -1 || rank >= world) return ctx->fail(RT_ERR_INVALID, "bad tile size / rank / world");
+    P = FramePlanes{pl->rgb, pl->z, pl->sample_count, pl->object_id, nullptr};
+    return RT_OK;
+}
+
+int rt_frame_pack(rt_ctx *ctx, const rt_frame_out *planes, int tile_size, int rank, int world, void *packed)
+{
+    if (!ctx) return RT_ERR_INVALID;
+    FramePlanes P;
+    if (int rc = exchange_args(ctx, planes, packed, tile_size, rank, world, P)) return rc;
+    if (rank < 0) return ctx->fail(RT_ERR_INVALID, "bad rank");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int W = ctx->camera.width, H = ctx->camera.height;
+    const uint32_t n = rt_frame_records(W, H, tile_size, world);
+    hipLaunchKernelGGL(k_frame_pack, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, P, W, H, tile_size, rank, world, n, (uint4 *)packed);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_frame_unpack(rt_ctx *ctx, const void *packed_all, int tile_size, int skip_rank, int world, const rt_frame_out *planes)
+{
+    if (!ctx) return RT_ERR_INVALID;
+    FramePlanes P;
+    if (int rc = exchange_args(ctx, planes, packed_all, tile_size, skip_rank, world, P)) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int W = ctx->camera.width, H = ctx->camera.height;
+    const uint32_t n = rt_frame_records(W, H, tile_size, world);
+    hipLaunchKernelGGL(k_frame_unpack, dim3((n + kBlock - 1) / kBlock, (unsigned)world), dim3(kBlock), 0, ctx->stream, (const uint4 *)packed_all, W, H,
+                       tile_size, skip_rank, world, n, P);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return RT_OK;
 }
 

@@ -12,8 +12,8 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-# bytes per pixel in the packed exchange buffer: rgb u8*3, z f32, sample_count i32, object_id i32
-PACK = 15
+# bytes per pixel in the exchange buffer: one record of four 32-bit words (r | g << 8 | b << 16, z, sample count, object id)
+PACK = 16
 
 
 def shard_pixels(width, height, tile_size, rank, world):
@@ -30,6 +30,26 @@ def shard_pixels(width, height, tile_size, rank, world):
     return np.concatenate(out) if out else np.zeros(0, np.int64)
 
 
+def frame_records(width, height, tile_size, world):
+    """Records per rank in the exchange buffer: every tile takes tile_size^2 (rt_frame_records)."""
+    tiles = -(-width // tile_size) * -(-height // tile_size)
+    return -(-tiles // world) * tile_size * tile_size
+
+
+def record_pixels(width, height, tile_size, rank, world):
+    """(records, pixels): which record of `rank`'s exchange array holds which pixel (the arithmetic of k_frame_pack)."""
+    tx = -(-width // tile_size)
+    ty = -(-height // tile_size)
+    per = tile_size * tile_size
+    s = np.arange(frame_records(width, height, tile_size, world), dtype=np.int64)
+    t = rank + (s // per) * world
+    o = s % per
+    x = (t % tx) * tile_size + o % tile_size
+    y = (t // tx) * tile_size + o // tile_size
+    ok = (t < tx * ty) & (x < width) & (y < height)
+    return s[ok], (y * width + x)[ok]
+
+
 class FrameBuffers:
     """Full-frame planes in the memory of `device` (torch tensors; the library writes through data_ptr())."""
 
@@ -41,40 +61,66 @@ class FrameBuffers:
         self.sample_count = torch.zeros((n,), dtype=torch.int32, device=device)
         self.object_id = torch.zeros((n,), dtype=torch.int32, device=device)
 
+    def pointers(self):
+        return (self.rgb.data_ptr(), self.z.data_ptr(), self.sample_count.data_ptr(), self.object_id.data_ptr())
+
 
 class FrameGather:
-    """Packs this rank's pixels, all-gathers, unpacks every rank's pixels into the full frame."""
+    """Packs this rank's pixels into 16-byte records, all-gathers, unpacks every other rank's records into the full frame.
 
-    def __init__(self, width, height, tile_size, rank, world, device):
-        self.world, self.rank = world, rank
-        lists = [shard_pixels(width, height, tile_size, r, world) for r in range(world)]
-        self.n_max = max(len(x) for x in lists)
-        self.idx = [torch.from_numpy(x.astype(np.int64)).to(device) for x in lists]
-        self.send = torch.zeros((self.n_max, PACK), dtype=torch.uint8, device=device)
-        self.recv = torch.zeros((world, self.n_max, PACK), dtype=torch.uint8, device=device)
-        # the other ranks' pixels in one go: rows of the flattened receive buffer and the pixels they belong to
-        rows = [r * self.n_max + np.arange(len(lists[r]), dtype=np.int64) for r in range(world) if r != rank]
-        dest = [lists[r].astype(np.int64) for r in range(world) if r != rank]
-        self.rows = torch.from_numpy(np.concatenate(rows) if rows else np.zeros(0, np.int64)).to(device)
-        self.dest = torch.from_numpy(np.concatenate(dest) if dest else np.zeros(0, np.int64)).to(device)
+    With a library context (GPU) the two steps are one kernel each (rt_frame_pack / rt_frame_unpack: the place of a
+    pixel in the exchange array is arithmetic, no index lists); without one (the CPU tests of the N > 1 path) the same
+    record layout is produced with torch indexing."""
+
+    def __init__(self, width, height, tile_size, rank, world, device, ctx=None):
+        self.world, self.rank, self.ctx, self.tile = world, rank, ctx, tile_size
+        self.n = frame_records(width, height, tile_size, world)
+        if world == 1:
+            return
+        self.send = torch.zeros((self.n, 4), dtype=torch.int32, device=device)
+        self.recv = torch.zeros((world, self.n, 4), dtype=torch.int32, device=device)
+        if ctx is None:
+            s, px = record_pixels(width, height, tile_size, rank, world)
+            self.my_s, self.my_px = torch.from_numpy(s).to(device), torch.from_numpy(px).to(device)
+            rows, dest = [], []
+            for r in range(world):
+                if r != rank:
+                    s, px = record_pixels(width, height, tile_size, r, world)
+                    rows.append(r * self.n + s)
+                    dest.append(px)
+            self.rows = torch.from_numpy(np.concatenate(rows)).to(device)
+            self.dest = torch.from_numpy(np.concatenate(dest)).to(device)
+
+    def pack(self, fb):
+        if self.ctx is not None:
+            self.ctx.frame_pack(fb.pointers(), self.tile, self.rank, self.world, self.send.data_ptr())
+            return
+        s, px = self.my_s, self.my_px
+        rgb = fb.rgb[px].to(torch.int32)
+        self.send.zero_()
+        self.send[s, 0] = rgb[:, 0] | (rgb[:, 1] << 8) | (rgb[:, 2] << 16)
+        self.send[s, 1] = fb.z[px].view(torch.int32)
+        self.send[s, 2] = fb.sample_count[px]
+        self.send[s, 3] = fb.object_id[px]
+
+    def unpack(self, fb):
+        if self.ctx is not None:
+            self.ctx.frame_unpack(self.recv.data_ptr(), self.tile, self.rank, self.world, fb.pointers())
+            return
+        blk = self.recv.view(-1, 4)[self.rows]
+        fb.rgb[self.dest] = torch.stack([blk[:, 0] & 255, (blk[:, 0] >> 8) & 255, (blk[:, 0] >> 16) & 255], 1).to(torch.uint8)
+        fb.z[self.dest] = blk[:, 1].contiguous().view(torch.float32)
+        fb.sample_count[self.dest] = blk[:, 2]
+        fb.object_id[self.dest] = blk[:, 3]
 
     def __call__(self, fb):
         if self.world == 1:
             return fb
-        mine = self.idx[self.rank]
-        n = len(mine)
-        s = self.send
-        s[:n, 0:3] = fb.rgb[mine]
-        s[:n, 3:7] = fb.z[mine].view(torch.uint8).reshape(n, 4)
-        s[:n, 7:11] = fb.sample_count[mine].view(torch.uint8).reshape(n, 4)
-        s[:n, 11:15] = fb.object_id[mine].view(torch.uint8).reshape(n, 4)
-        dist.all_gather_into_tensor(self.recv.view(-1), s.view(-1))
-        blk = self.recv.view(-1, PACK)[self.rows]
-        m = len(self.dest)
-        fb.rgb[self.dest] = blk[:, 0:3]
-        fb.z[self.dest] = blk[:, 3:7].contiguous().view(torch.float32).reshape(m)
-        fb.sample_count[self.dest] = blk[:, 7:11].contiguous().view(torch.int32).reshape(m)
-        fb.object_id[self.dest] = blk[:, 11:15].contiguous().view(torch.int32).reshape(m)
+        self.pack(fb)  # on the library's stream, finished when it returns
+        dist.all_gather_into_tensor(self.recv.view(-1), self.send.view(-1))
+        if self.ctx is not None:
+            torch.cuda.current_stream().synchronize()  # the unpack kernel runs on the library's stream
+        self.unpack(fb)
         return fb
 
 
@@ -104,6 +150,8 @@ class PhotonFill:
     def _emit_gpu(self, pp, which, path_begin, path_count, capacity):
         if self._scratch is None or self._scratch.shape[0] < capacity:
             self._scratch = torch.empty((max(1, capacity), 32), dtype=torch.uint8, device=self.device)
+        # the library writes the scratch on its own stream: copies out of it that torch queued earlier must be through
+        torch.cuda.current_stream().synchronize()
         _, stored = self.ctx.photons_emit(pp, which, path_begin, path_count, capacity, device_ptr=self._scratch.data_ptr())
         c = self.ctx.counters()
         self.stats["rays"] += int(c.closest_rays)

@@ -21,7 +21,7 @@ SYMBOLS = (
     "rt_trace", "rt_trace_shadow", "rt_trace_brief", "rt_trace_brief_noalloc", "rt_trace_paths", "rt_get_counters", "rt_set_counting",
     "rt_scene_load_xml", "rt_scene_from_xml_string", "rt_scene_host_desc", "rt_scene_host_camera",
     "rt_scene_host_free", "rt_scene_host_set_mesh", "rt_bvh_build", "rt_free",
-    "rt_cancel", "rt_progress", "rt_photons_emit", "rt_photons_build", "rt_photons_fill", "rt_photons_download", "rt_photons_irradiance",
+    "rt_cancel", "rt_progress", "rt_frame_records", "rt_frame_pack", "rt_frame_unpack", "rt_photons_emit", "rt_photons_build", "rt_photons_fill", "rt_photons_download", "rt_photons_irradiance",
 )
 
 _lib = None
@@ -50,6 +50,10 @@ def load():
     L.rt_scene_upload.argtypes = [vp, C.POINTER(abi.SceneDesc)]
     L.rt_camera_set.argtypes = [vp, C.POINTER(abi.Camera)]
     L.rt_render.argtypes = [vp, C.POINTER(abi.RenderParams), C.POINTER(abi.FrameOut)]
+    L.rt_frame_records.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
+    L.rt_frame_records.restype = C.c_uint32
+    L.rt_frame_pack.argtypes = [vp, C.POINTER(abi.FrameOut), C.c_int, C.c_int, C.c_int, vp]
+    L.rt_frame_unpack.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(abi.FrameOut)]
     L.rt_cancel.argtypes = [vp]
     L.rt_progress.argtypes = [vp, C.POINTER(abi.ProgressInfo)]
     L.rt_trace.argtypes = [vp, abi.f32p, C.c_int, C.POINTER(abi.Hit)]
@@ -199,6 +203,15 @@ class Context:
         """Render into device memory; arguments are device addresses (0 = plane not wanted)."""
         out = abi.FrameOut(rgb or None, z or None, sample_count or None, object_id or None, linear or None, 1)
         self._check(self._L.rt_render(self._h, C.byref(params), C.byref(out)))
+
+    def frame_pack(self, planes, tile_size, rank, world, packed_ptr):
+        """planes = (rgb, z, sample_count, object_id) device addresses -> 16-byte records of this rank's pixels at packed_ptr"""
+        out = abi.FrameOut(planes[0], planes[1], planes[2], planes[3], None, 1)
+        self._check(self._L.rt_frame_pack(self._h, C.byref(out), tile_size, rank, world, packed_ptr))
+
+    def frame_unpack(self, packed_all_ptr, tile_size, skip_rank, world, planes):
+        out = abi.FrameOut(planes[0], planes[1], planes[2], planes[3], None, 1)
+        self._check(self._L.rt_frame_unpack(self._h, packed_all_ptr, tile_size, skip_rank, world, C.byref(out)))
 
     def cancel(self):
         """rt_cancel: callable from another thread while render() runs."""

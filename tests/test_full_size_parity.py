@@ -277,3 +277,50 @@ def test_cancel_and_progress(scene):
         assert dt < 0.6 * full + 0.05, f"cancelled call took {dt:.3f} s, the whole frame takes {full:.3f} s"
     finally:
         c.close()
+
+
+# ---------------------------------------------------------------- frame exchange between GPUs, on one GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,tile,world", [(200, 120, 16, 3), (70, 45, 8, 2), (1920, 1080, 16, 8)])
+def test_frame_pack_unpack_kernels(w, h, tile, world):
+    """rt_frame_pack / rt_frame_unpack (what FrameGather runs on a GPU) against the torch form of the same record
+    layout that the gloo tests of the multi-process path exercise, and the round trip shard -> records -> frame."""
+    import torch
+    from raytracer_amd.dist import FrameBuffers, FrameGather, frame_records
+    dev = torch.device("cuda", 0)
+    c = lib.Context(0)
+    try:
+        hs = lib.HostScene.from_string(scenes.cornell_scene_xml())
+        c.upload(hs.desc)
+        c.set_camera(hs.camera, w, h)
+        kw = dict(seed=3, min_spp=1, max_spp=1, max_bounces=2, tile_size=tile)
+        whole = c.render(abi.default_params(**kw))
+        n = frame_records(w, h, tile, world)
+        assert n == lib.load().rt_frame_records(w, h, tile, world)
+        recv = torch.zeros((world, n, 4), dtype=torch.int32, device=dev)
+        fbs = []
+        for r in range(world):
+            fb = FrameBuffers(w, h, dev)
+            fb.rgb[:] = 0xAB; fb.z[:] = -1.0; fb.sample_count[:] = -7; fb.object_id[:] = -99  # poison what the rank does not own
+            torch.cuda.synchronize()
+            c.render_device(abi.default_params(tile_rank=r, tile_world=world, **kw), rgb=fb.rgb.data_ptr(), z=fb.z.data_ptr(),
+                            sample_count=fb.sample_count.data_ptr(), object_id=fb.object_id.data_ptr())
+            g_gpu = FrameGather(w, h, tile, r, world, dev, ctx=c)
+            g_ref = FrameGather(w, h, tile, r, world, dev)  # torch indexing
+            g_gpu.pack(fb)
+            g_ref.pack(fb)
+            torch.cuda.synchronize()
+            assert torch.equal(g_gpu.send, g_ref.send), f"rank {r}: packed records"
+            recv[r] = g_gpu.send
+            fbs.append((fb, g_gpu))
+        torch.cuda.synchronize()
+        for r, (fb, g) in enumerate(fbs):
+            g.recv.copy_(recv)
+            torch.cuda.synchronize()
+            g.unpack(fb)
+            assert np.array_equal(fb.rgb.cpu().numpy().reshape(h, w, 3), whole.rgb), f"rank {r}"
+            assert np.array_equal(fb.z.cpu().numpy().view(np.uint32).reshape(h, w), whole.z.view(np.uint32))
+            assert np.array_equal(fb.sample_count.cpu().numpy().reshape(h, w), whole.sample_count)
+            assert np.array_equal(fb.object_id.cpu().numpy().reshape(h, w), whole.object_id)
+    finally:
+        c.close()
