@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""tests/prof_collect_headline.py TAG SQTAG NAME: condense gpurun_out/TAG (tests/prof_round.sh) and gpurun_out/SQTAG
-(tests/prof_sq.sh) of the default bench command into profiles/NAME_kernel_stats.csv, NAME_bench_under_rocprof.json and
-NAME_pmc_k_paths.json (what bench.py's roofline.traffic reads)."""
+"""tests/prof_collect_headline.py TAG SQTAG NAME [KERNEL]: condense gpurun_out/TAG (tests/prof_round.sh) and
+gpurun_out/SQTAG (tests/prof_sq.sh) of the default bench command into profiles/NAME_kernel_stats.csv,
+NAME_bench_under_rocprof.json and NAME_pmc_KERNEL.json (what bench.py's roofline.traffic reads).  KERNEL is the
+dominant kernel of the frame: k_rays (wavefront pipeline, the default for scenes with meshes) or k_paths."""
 import csv
 import glob
 import json
@@ -11,6 +12,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, sqtag, name = sys.argv[1:4]
+KERNEL = sys.argv[4] if len(sys.argv) > 4 else "k_rays"
 src = os.path.join(ROOT, "gpurun_out", tag)
 prof = os.path.join(ROOT, "profiles")
 shutil.copy(glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)[0], os.path.join(prof, f"{name}_kernel_stats.csv"))
@@ -24,7 +26,7 @@ def sums(directory, want_timed=True):
     for f in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
-            if "k_paths<false" not in k:
+            if KERNEL + "<false" not in k:
                 continue
             kernel = k.split("(")[0].replace("void ", "")
             out[r["Counter_Name"]] = out.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
@@ -33,14 +35,16 @@ def sums(directory, want_timed=True):
 
 
 mem = {}
+launches = 1
 for sub in ("fetch", "write", "cache", "rdreq", "wrreq"):
-    d, kernel, _ = sums(os.path.join(src, sub))
+    d, kernel, disp = sums(os.path.join(src, sub))
     mem.update(d)
+    launches = max(launches, len(disp))
 sq, _, _ = sums(os.path.join(ROOT, "gpurun_out", sqtag))
 out = {
     "kernel": kernel,
     "workload": json.loads(line)["config"]["workload"],
-    "launches_profiled": 1,
+    "launches_profiled": launches,
     "command": "rocprofv3 --pmc <one block per pass> -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline (tests/prof_round.sh, tests/prof_sq.sh)",
     "memory_side": {
         "read_bytes": 2.0 * mem["FETCH_SIZE"] * 1024,
@@ -51,6 +55,7 @@ out = {
     "tcc": {k: v for k, v in mem.items() if k.startswith("TC")},
     "sq": sq,
 }
-json.dump(out, open(os.path.join(prof, f"{name}_pmc_k_paths.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(prof, f"{name}_pmc_{KERNEL}.json"), "w"), indent=1)
 print(json.dumps(out["memory_side"], indent=1))
-print("lanes per VALU instruction", sq["SQ_THREAD_CYCLES_VALU"] / sq["SQ_INSTS_VALU"])
+print("launches in one frame", launches)
+print("lanes per VALU instruction", sq["SQ_THREAD_CYCLES_VALU"] / sq["SQ_ACTIVE_INST_VALU"])
