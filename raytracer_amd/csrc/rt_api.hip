@@ -3,7 +3,7 @@
 #include "device/wavefront.h"
 #include <hipcub/hipcub.hpp>
 #include "device/whitted.h"
-#include "host/photon_map.h"
+#include "device/kdbuild.h"
 #include "rt_mi355x.h"
 
 #include <algorithm>
@@ -1423,22 +1423,62 @@ int rt_photons_build(rt_ctx *ctx, int which, const rt_photon *photons, uint32_t 
     ctx->pmap_n[which] = 0;
     ctx->pmap_flags = -1;
     if (n == 0) return RT_OK;
-    std::vector<rt_photon> raw;
-    const rt_photon *src = photons;
-    if (device_memory) {
-        raw.resize(n);
-        HIP_TRY(ctx, hipMemcpy(raw.data(), photons, (size_t)n * sizeof(rt_photon), hipMemcpyDeviceToHost));
-        src = raw.data();
+    hipStream_t st = ctx->stream;
+    DeviceBuf staged;
+    const rt_photon *d_in = photons;
+    if (!device_memory) {
+        HIP_TRY(ctx, staged.reserve((size_t)n * sizeof(rt_photon)));
+        HIP_TRY(ctx, hipMemcpyAsync(staged.p, photons, (size_t)n * sizeof(rt_photon), hipMemcpyHostToDevice, st));
+        d_in = staged.as<rt_photon>();
     }
-    for (uint32_t i = 0; i < n; ++i) {
-        const rt_photon &p = src[i];
-        if (!(std::isfinite(p.pos[0]) && std::isfinite(p.pos[1]) && std::isfinite(p.pos[2])))
-            return ctx->fail(RT_ERR_INVALID, "photon %u has a non-finite position", i); // the quick-select would not terminate
-    }
-    std::vector<rt_photon> tree;
-    rt::build_photon_tree(src, n, tree);
     HIP_TRY(ctx, ctx->d_pmap[which].reserve(((size_t)n + 1) * sizeof(rt_photon)));
-    HIP_TRY(ctx, hipMemcpy(ctx->pmap(which), tree.data(), (size_t)n * sizeof(rt_photon), hipMemcpyHostToDevice));
+    // working arrays of the build: positions as three arrays plus the photon ids, the scratch of the partition steps,
+    // the boxes of the nodes that have children (heap index <= n / 2), six words for the root box and one flag
+    DeviceBuf work;
+    const size_t n1 = ((size_t)n + 1 + 63) & ~(size_t)63, n_boxes = ((size_t)n / 2 + 2) * 6;
+    HIP_TRY(ctx, work.reserve((6 * n1 + n_boxes + 64) * sizeof(float)));
+    rtd::KdArrays A{};
+    A.x = work.as<float>(); A.y = A.x + n1; A.z = A.y + n1;
+    A.id = (uint32_t *)(A.z + n1); A.lpos = A.id + n1; A.rpos = A.lpos + n1;
+    A.boxes = (float *)(A.rpos + n1);
+    uint32_t *d_box_bits = (uint32_t *)(A.boxes + n_boxes), *d_bad = d_box_bits + 6;
+    A.in = d_in; A.out = ctx->pmap(which); A.n = n;
+    A.scale = 1.0f / (float)(int)n; // ScalePhotonPowers(1 / NumPhotons()) (src/photonmap.h:82)
+    const uint32_t init_words[7] = {0x80000000u, 0x80000000u, 0x80000000u, 0x80000000u, 0x80000000u, 0x80000000u, 0u};
+    HIP_TRY(ctx, hipMemcpyAsync(d_box_bits, init_words, sizeof init_words, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipEventRecord(ctx->evk0, st));
+    {
+        const uint32_t blocks = (uint32_t)std::min<size_t>(((size_t)n + 255) / 256, (size_t)ctx->n_cu * 8);
+        hipLaunchKernelGGL(rtd::k_kd_init, dim3(blocks), dim3(256), 0, st, A, d_box_bits, d_bad);
+        hipLaunchKernelGGL(rtd::k_kd_root_box, dim3(1), dim3(64), 0, st, A, (const uint32_t *)d_box_bits);
+    }
+    uint32_t bad = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (bad) return ctx->fail(RT_ERR_INVALID, "a photon has a non-finite position"); // the quick-select would not terminate
+    // one launch per level while the level's largest segment (its leftmost) is worth a workgroup, then one lane per segment
+    for (int level = 0; level < rtd::kKdMaxLevels && n >= 2; ++level) {
+        const uint32_t first = 1u << level;
+        if (first > n) break;
+        const uint32_t nodes = std::min<uint32_t>(first, n - first + 1);
+        int s0, e0;
+        if (!rtd::kd_segment(n, first, s0, e0)) break; // nothing left with two or more photons
+        const int largest = e0 - s0 + 1;
+        if (largest <= rtd::kKdTiny) {
+            hipLaunchKernelGGL(rtd::k_kd_tiny, dim3((nodes + 63) / 64), dim3(64), 0, st, A, first, nodes);
+            break;
+        }
+        if (largest > 16384) hipLaunchKernelGGL(rtd::k_kd_level<1024>, dim3(nodes), dim3(1024), 0, st, A, first, nodes);
+        else if (largest > 1024) hipLaunchKernelGGL(rtd::k_kd_level<256>, dim3(nodes), dim3(256), 0, st, A, first, nodes);
+        else hipLaunchKernelGGL(rtd::k_kd_level<64>, dim3(nodes), dim3(64), 0, st, A, first, nodes);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->evk1, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    float build_ms = 0;
+    HIP_TRY(ctx, hipEventElapsedTime(&build_ms, ctx->evk0, ctx->evk1));
+    ctx->counters = rt_counters{};
+    ctx->counters.kernel_ms = build_ms;
     int levels = 1;
     while ((1u << levels) <= n) ++levels; // tree height
     if (int rc = ensure_stack_levels(ctx, levels + 1)) return rc;
