@@ -165,14 +165,114 @@ template <int T> RT_DEV unsigned long long kd_block_scan(unsigned long long v, u
     return base + inc - v;
 }
 
+struct KdShared {
+    unsigned long long wave[16];
+    unsigned long long final; // first L position of the step that is not swapped << 32 | its rank
+    int abort;
+};
+
+// One partition step seen from one workgroup that owns the positions [a, e] of the step's range [left, right].
+// count: L positions | R positions << 32 of the slice (every thread gets the sum).
+template <int T, int V>
+RT_DEV unsigned long long kd_slice_count(const float *key, float v, int a, int e, int left, int right, KdShared &sh)
+{
+    uint32_t nl = 0, nr = 0;
+    for (int base = a + (int)threadIdx.x; base <= e; base += T * V) {
+        float k[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) { const int p = base + j * T; k[j] = p <= e ? key[p] : 0.0f; }
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const int p = base + j * T;
+            if (p <= e) { nl += k[j] >= v ? 1u : 0u; nr += (p < right && (k[j] <= v || p == left)) ? 1u : 0u; }
+        }
+    }
+    unsigned long long total;
+    kd_block_scan<T>((unsigned long long)nl | ((unsigned long long)nr << 32), sh.wave, total);
+    return total;
+}
+
+// rank: with run_l L positions and run_r R positions before the slice and total_r R positions in the whole range, note
+// the swapped positions of the slice by rank in lpos / rpos and the first L position that stays in sh.final.
+template <int T, int V>
+RT_DEV void kd_slice_rank(const KdArrays &A, const float *key, float v, int a, int e, int left, int right,
+                          uint32_t run_l, uint32_t run_r, uint32_t total_r, KdShared &sh)
+{
+    unsigned long long mine = ~0ull;
+    for (int base = a; base <= e; base += T * V) {
+        const int p0 = base + (int)threadIdx.x * V; // V neighbours per thread: one scan per T * V positions
+        float k[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) k[j] = (p0 + j) <= e ? key[p0 + j] : 0.0f;
+        uint32_t ml = 0, mr = 0;
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const int p = p0 + j;
+            if (p <= e) {
+                if (k[j] >= v) ml |= 1u << j;
+                if (p < right && (k[j] <= v || p == left)) mr |= 1u << j;
+            }
+        }
+        unsigned long long total;
+        const unsigned long long ex = kd_block_scan<T>((unsigned long long)__popc(ml) | ((unsigned long long)__popc(mr) << 32), sh.wave, total);
+        uint32_t c_l = run_l + (uint32_t)ex;            // L positions before p
+        uint32_t seen_r = run_r + (uint32_t)(ex >> 32); // R positions before p
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const int p = p0 + j;
+            const bool f_l = (ml >> j) & 1u, f_r = (mr >> j) & 1u;
+            const uint32_t r_r = total_r - seen_r - (f_r ? 1u : 0u); // R positions after p
+            if (f_l) {
+                if (r_r > c_l) A.lpos[left + (int)c_l] = (uint32_t)p;
+                else if (mine == ~0ull) mine = ((unsigned long long)(uint32_t)p << 32) | c_l;
+            }
+            if (f_r && c_l > r_r) A.rpos[left + (int)r_r] = (uint32_t)p;
+            c_l += f_l ? 1u : 0u; seen_r += f_r ? 1u : 0u;
+        }
+        run_l += (uint32_t)total; run_r += (uint32_t)(total >> 32);
+    }
+    if (mine != ~0ull) atomicMin(&sh.final, mine);
+}
+
+// swap: the step's K swaps and the pivot's, thread `me` of `crowd`.  The pivot goes to the first L position that stays
+// or, if i meets it first, to where the last swap moved a key up; whoever does that last swap then moves the pivot too.
+RT_DEV int kd_step_swaps(const KdArrays &A, unsigned long long final, int left, int right, uint32_t me, uint32_t crowd)
+{
+    const uint32_t K = (uint32_t)final;
+    int ifinal = (int)(final >> 32);
+    bool at_r = false;
+    if (K) { const int r = (int)A.rpos[left + (int)K - 1]; if (r <= ifinal) { ifinal = r; at_r = true; } }
+    for (uint32_t k = me; k <= K; k += crowd) {
+        if (k < K) {
+            kd_swap(A, (int)A.lpos[left + (int)k], (int)A.rpos[left + (int)k]);
+            if (at_r && k == K - 1) kd_swap(A, ifinal, right);
+        } else if (!at_r) kd_swap(A, ifinal, right);
+    }
+    return ifinal;
+}
+
+// The quick-select of one segment by one workgroup, from the range [left, right] on.
+template <int T, int V>
+RT_DEV void kd_select_alone(const KdArrays &A, const float *key, int left, int right, int median, KdShared &sh)
+{
+    while (right > left) {
+        const float v = key[right];
+        if (threadIdx.x == 0) sh.final = ~0ull;
+        const unsigned long long cnt = kd_slice_count<T, V>(key, v, left, right, left, right, sh);
+        kd_slice_rank<T, V>(A, key, v, left, right, left, right, 0u, 0u, (uint32_t)(cnt >> 32), sh);
+        __syncthreads();
+        const int ifinal = kd_step_swaps(A, sh.final, left, right, threadIdx.x, T);
+        __syncthreads();
+        if (ifinal >= median) right = ifinal - 1;
+        if (ifinal <= median) left = ifinal + 1;
+    }
+}
+
 // One level of the tree: workgroup b balances the segment of heap node first_index + b.
-template <int T>
+template <int T, int V>
 __global__ __launch_bounds__(T) void k_kd_level(KdArrays A, uint32_t first_index, uint32_t n_nodes)
 {
-    __shared__ unsigned long long s_wave[T / 64];
-    __shared__ int s_left, s_right;
-    __shared__ unsigned long long s_final; // first L position that is not swapped << 32 | its rank
-    __shared__ uint32_t s_totalR;
+    __shared__ KdShared sh;
     const uint32_t index = first_index + blockIdx.x;
     if (blockIdx.x >= n_nodes) return;
     int start, end;
@@ -182,54 +282,104 @@ __global__ __launch_bounds__(T) void k_kd_level(KdArrays A, uint32_t first_index
     const int axis = kd_axis(box);
     const int median = kd_median(start, end);
     float *key = axis == 0 ? A.x : axis == 1 ? A.y : A.z;
-    if (threadIdx.x == 0) { s_left = start; s_right = end; }
-    __syncthreads();
-    for (;;) {
-        const int left = s_left, right = s_right;
-        if (!(right > left)) break;
-        const float v = key[right];
-        // the R positions: how many there are (the pass below needs the count after each position)
-        uint32_t cnt = 0;
-        for (int p = left + (int)threadIdx.x; p < right; p += T) cnt += (key[p] <= v || p == left) ? 1u : 0u;
-        if (threadIdx.x == 0) { s_totalR = 0; s_final = ~0ull; }
-        __syncthreads();
-        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o, 64);
-        if ((threadIdx.x & 63u) == 0 && cnt) atomicAdd(&s_totalR, cnt);
-        __syncthreads();
-        const uint32_t totalR = s_totalR;
-        // ranks of the L and R positions, who is swapped, where the pivot goes
-        uint32_t runL = 0, runR = 0;
-        for (int base = left; base <= right; base += T) {
-            const int p = base + (int)threadIdx.x;
-            const bool in = p <= right;
-            const float kp = in ? key[p] : 0.0f;
-            const bool fL = in && kp >= v;
-            const bool fR = in && p < right && (kp <= v || p == left);
-            unsigned long long total;
-            const unsigned long long ex = kd_block_scan<T>((fL ? 1ull : 0ull) | ((fR ? 1ull : 0ull) << 32), s_wave, total);
-            const uint32_t cL = runL + (uint32_t)ex;                                   // L positions before p
-            const uint32_t rR = totalR - (runR + (uint32_t)(ex >> 32) + (fR ? 1u : 0u)); // R positions after p
-            if (fL) {
-                if (rR > cL) A.lpos[left + (int)cL] = (uint32_t)p;
-                else atomicMin(&s_final, ((unsigned long long)(uint32_t)p << 32) | cL);
-            }
-            if (fR && cL > rR) A.rpos[left + (int)rR] = (uint32_t)p;
-            runL += (uint32_t)total; runR += (uint32_t)(total >> 32);
-        }
-        __syncthreads();
-        const uint32_t K = (uint32_t)s_final; // the L positions before the first one not swapped are the swapped ones
-        int ifinal = (int)(s_final >> 32);
-        if (K) ifinal = min(ifinal, (int)A.rpos[left + (int)K - 1]); // i stops earlier at the key its last swap moved up
-        for (uint32_t k = threadIdx.x; k < K; k += T) kd_swap(A, (int)A.lpos[left + (int)k], (int)A.rpos[left + (int)k]);
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            kd_swap(A, ifinal, right);
-            if (ifinal >= median) s_right = ifinal - 1;
-            if (ifinal <= median) s_left = ifinal + 1;
-        }
-        __syncthreads();
-    }
+    kd_select_alone<T, V>(A, key, start, end, median, sh);
     if (threadIdx.x == 0) {
+        kd_emit(A, index, median, axis);
+        kd_children(A, index, start, end, median, axis, box, key[median]);
+    }
+}
+
+// The top levels have fewer segments than the chip has compute units: there `crowd` workgroups share a segment.  Each
+// owns a slice of the step's range; they meet three times per step (counts known, ranks known, swaps done) at a
+// barrier of their own in global memory.  The whole grid must be resident at once (at most one workgroup per compute
+// unit is launched); a workgroup that waits longer than any step can take raises *give_up and leaves, and so do all
+// others of its group as they notice.
+struct KdCrowd {
+    unsigned long long arrived; // workgroups that have reached a barrier, counted up for ever
+    unsigned long long final;   // as KdShared::final, over all slices
+    unsigned long long counts[1]; // [crowd] L | R << 32 of each slice
+};
+constexpr int kKdAloneBelow = 16384; // ranges this short are finished by the group's first workgroup alone
+
+RT_DEV bool kd_crowd_barrier(KdCrowd *c, unsigned long long target, uint32_t *give_up, KdShared &sh)
+{
+    __threadfence(); // what this thread wrote is visible to the device before its workgroup is counted
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&c->arrived, 1ull);
+        uint32_t spins = 0;
+        while (__hip_atomic_load(&c->arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(2);
+            if ((++spins & 1023u) == 0 && (spins > (1u << 26) || __hip_atomic_load(give_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                atomicExch(give_up, 1u);
+                sh.abort = 1;
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    __threadfence(); // and nothing read from here on is older than the barrier
+    return sh.abort == 0;
+}
+
+template <int T, int V>
+__global__ __launch_bounds__(T) void k_kd_level_crowd(KdArrays A, uint32_t first_index, uint32_t crowd, unsigned long long *state, uint32_t *give_up)
+{
+    __shared__ KdShared sh;
+    const uint32_t g = blockIdx.x / crowd, b = blockIdx.x % crowd;
+    const uint32_t index = first_index + g;
+    KdCrowd *C = (KdCrowd *)(state + (size_t)g * (2 + crowd));
+    int start, end;
+    if (!kd_segment(A.n, index, start, end)) return; // the whole group leaves
+    float box[6];
+    for (int k = 0; k < 6; ++k) box[k] = A.boxes[(size_t)index * 6 + k];
+    const int axis = kd_axis(box);
+    const int median = kd_median(start, end);
+    float *key = axis == 0 ? A.x : axis == 1 ? A.y : A.z;
+    if (threadIdx.x == 0) sh.abort = 0;
+    __syncthreads();
+    int left = start, right = end;
+    unsigned long long meetings = 0;
+    while (right > left) {
+        const int m = right - left + 1;
+        if (m <= kKdAloneBelow) {
+            if (b != 0) return;
+            kd_select_alone<T, V>(A, key, left, right, median, sh);
+            break;
+        }
+        const float v = key[right];
+        const int per = (m + (int)crowd - 1) / (int)crowd;
+        const int a = left + (int)b * per, e = min(right, a + per - 1);
+        if (threadIdx.x == 0) sh.final = ~0ull;
+        const unsigned long long cnt = kd_slice_count<T, V>(key, v, a, e, left, right, sh);
+        if (threadIdx.x == 0) {
+            C->counts[b] = cnt;
+            if (b == 0) C->final = ~0ull;
+        }
+        if (!kd_crowd_barrier(C, ++meetings * crowd, give_up, sh)) return;
+        // slices before mine, and all of them
+        unsigned long long before = 0, all = 0;
+        {
+            unsigned long long mine_before = 0, mine_all = 0;
+            for (uint32_t j = threadIdx.x; j < crowd; j += T) {
+                const unsigned long long c = __hip_atomic_load(&C->counts[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                mine_all += c; if (j < b) mine_before += c;
+            }
+            unsigned long long t;
+            kd_block_scan<T>(mine_before, sh.wave, t); before = t;
+            kd_block_scan<T>(mine_all, sh.wave, t); all = t;
+        }
+        kd_slice_rank<T, V>(A, key, v, a, e, left, right, (uint32_t)before, (uint32_t)(before >> 32), (uint32_t)(all >> 32), sh);
+        __syncthreads();
+        if (threadIdx.x == 0 && sh.final != ~0ull) atomicMin(&C->final, sh.final);
+        if (!kd_crowd_barrier(C, ++meetings * crowd, give_up, sh)) return;
+        const unsigned long long final = __hip_atomic_load(&C->final, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int ifinal = kd_step_swaps(A, final, left, right, b * T + threadIdx.x, crowd * T);
+        if (!kd_crowd_barrier(C, ++meetings * crowd, give_up, sh)) return;
+        if (ifinal >= median) right = ifinal - 1;
+        if (ifinal <= median) left = ifinal + 1;
+    }
+    if (b == 0 && threadIdx.x == 0) {
         kd_emit(A, index, median, axis);
         kd_children(A, index, start, end, median, axis, box, key[median]);
     }

@@ -1436,12 +1436,14 @@ int rt_photons_build(rt_ctx *ctx, int which, const rt_photon *photons, uint32_t 
     // the boxes of the nodes that have children (heap index <= n / 2), six words for the root box and one flag
     DeviceBuf work;
     const size_t n1 = ((size_t)n + 1 + 63) & ~(size_t)63, n_boxes = ((size_t)n / 2 + 2) * 6;
-    HIP_TRY(ctx, work.reserve((6 * n1 + n_boxes + 64) * sizeof(float)));
+    const size_t crowd_bytes = 3 * 256 * sizeof(unsigned long long); // per group of a crowd launch: two words and one per workgroup
+    HIP_TRY(ctx, work.reserve((6 * n1 + n_boxes + 64) * sizeof(float) + crowd_bytes));
     rtd::KdArrays A{};
     A.x = work.as<float>(); A.y = A.x + n1; A.z = A.y + n1;
     A.id = (uint32_t *)(A.z + n1); A.lpos = A.id + n1; A.rpos = A.lpos + n1;
     A.boxes = (float *)(A.rpos + n1);
     uint32_t *d_box_bits = (uint32_t *)(A.boxes + n_boxes), *d_bad = d_box_bits + 6;
+    unsigned long long *d_crowd = (unsigned long long *)(d_box_bits + 64);
     A.in = d_in; A.out = ctx->pmap(which); A.n = n;
     A.scale = 1.0f / (float)(int)n; // ScalePhotonPowers(1 / NumPhotons()) (src/photonmap.h:82)
     const uint32_t init_words[7] = {0x80000000u, 0x80000000u, 0x80000000u, 0x80000000u, 0x80000000u, 0x80000000u, 0u};
@@ -1456,7 +1458,11 @@ int rt_photons_build(rt_ctx *ctx, int which, const rt_photon *photons, uint32_t 
     HIP_TRY(ctx, hipMemcpyAsync(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     if (bad) return ctx->fail(RT_ERR_INVALID, "a photon has a non-finite position"); // the quick-select would not terminate
-    // one launch per level while the level's largest segment (its leftmost) is worth a workgroup, then one lane per segment
+    // One launch per level.  While a level has fewer segments than the chip has compute units and they are long, a
+    // crowd of workgroups shares each segment; then a workgroup per segment, sized to the level's largest segment (its
+    // leftmost); segments of kKdTiny photons or fewer are finished by one lane each.
+    uint32_t grid_max = 1;
+    while (grid_max * 2 <= (uint32_t)std::min(ctx->n_cu, 256)) grid_max *= 2; // every workgroup of a crowd launch must be resident
     for (int level = 0; level < rtd::kKdMaxLevels && n >= 2; ++level) {
         const uint32_t first = 1u << level;
         if (first > n) break;
@@ -1468,13 +1474,20 @@ int rt_photons_build(rt_ctx *ctx, int which, const rt_photon *photons, uint32_t 
             hipLaunchKernelGGL(rtd::k_kd_tiny, dim3((nodes + 63) / 64), dim3(64), 0, st, A, first, nodes);
             break;
         }
-        if (largest > 16384) hipLaunchKernelGGL(rtd::k_kd_level<1024>, dim3(nodes), dim3(1024), 0, st, A, first, nodes);
-        else if (largest > 1024) hipLaunchKernelGGL(rtd::k_kd_level<256>, dim3(nodes), dim3(256), 0, st, A, first, nodes);
-        else hipLaunchKernelGGL(rtd::k_kd_level<64>, dim3(nodes), dim3(64), 0, st, A, first, nodes);
+        const uint32_t crowd = grid_max >> std::min(level, 31);
+        if (crowd >= 2 && largest > rtd::kKdAloneBelow) {
+            HIP_TRY(ctx, hipMemsetAsync(d_crowd, 0, crowd_bytes, st));
+            hipLaunchKernelGGL((rtd::k_kd_level_crowd<1024, 8>), dim3(first * crowd), dim3(1024), 0, st, A, first, crowd, d_crowd, d_bad);
+        }
+        else if (largest > 16384) hipLaunchKernelGGL((rtd::k_kd_level<1024, 8>), dim3(nodes), dim3(1024), 0, st, A, first, nodes);
+        else if (largest > 2048) hipLaunchKernelGGL((rtd::k_kd_level<256, 8>), dim3(nodes), dim3(256), 0, st, A, first, nodes);
+        else hipLaunchKernelGGL((rtd::k_kd_level<64, 4>), dim3(nodes), dim3(64), 0, st, A, first, nodes);
     }
+    HIP_TRY(ctx, hipMemcpyAsync(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->evk1, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (bad) return ctx->fail(RT_ERR_HIP, "kd-tree build: workgroups sharing a segment waited for each other in vain (were they not all resident?)");
     float build_ms = 0;
     HIP_TRY(ctx, hipEventElapsedTime(&build_ms, ctx->evk0, ctx->evk1));
     ctx->counters = rt_counters{};
