@@ -303,9 +303,9 @@ constexpr int kKdAloneBelow = 16384; // ranges this short are finished by the gr
 
 RT_DEV bool kd_crowd_barrier(KdCrowd *c, unsigned long long target, uint32_t *give_up, KdShared &sh)
 {
-    __threadfence(); // what this thread wrote is visible to the device before its workgroup is counted
-    __syncthreads();
+    __syncthreads(); // the stores of the whole workgroup have been issued and acknowledged ...
     if (threadIdx.x == 0) {
+        __threadfence(); // ... and are made visible to the device before the workgroup is counted
         atomicAdd(&c->arrived, 1ull);
         uint32_t spins = 0;
         while (__hip_atomic_load(&c->arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
@@ -316,9 +316,9 @@ RT_DEV bool kd_crowd_barrier(KdCrowd *c, unsigned long long target, uint32_t *gi
                 break;
             }
         }
+        __threadfence(); // nothing this compute unit reads from here on is older than the barrier
     }
     __syncthreads();
-    __threadfence(); // and nothing read from here on is older than the barrier
     return sh.abort == 0;
 }
 
