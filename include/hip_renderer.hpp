@@ -88,27 +88,28 @@ public:
     bool IsRenderDone() const { return numRenderedPixels >= width * height; }
     void IncrementNumRenderPixel(int n) { numRenderedPixels += n; }
 
-    void ComputeZBufferImage() { ComputeImage<float, true>(zbufferImg, zbuffer, BIGFLOAT); }
-    int ComputeSampleCountImage() { return ComputeImage<int, false>(sampleCountImg, sampleCount, 0); }
+    // 8-bit views of the depth and sample-count planes (src/renderer.h:84-105): values spread over 0..255 between the
+    // smallest and largest entry that is not the plane's "nothing here" value; depth is shown near = bright.
+    void ComputeZBufferImage() { SpreadToBytes(zbuffer, BIGFLOAT, true, zbufferImg); }
+    int ComputeSampleCountImage() { return SpreadToBytes(sampleCount, 0, false, sampleCountImg); }
 
 private:
-    // min/max normalisation to 8 bits, skipping `skipv` (src/renderer.h:84-105)
-    template <typename T, bool invert> T ComputeImage(std::vector<uint8_t> &out, std::vector<T> &data, T skipv)
+    template <typename T> static T SpreadToBytes(const std::vector<T> &plane, T nothing, bool nearIsBright, std::vector<uint8_t> &bytes)
     {
-        T vmin = std::numeric_limits<T>::max(), vmax = T(0);
-        for (const T &d : data) {
-            if (d == skipv) continue;
-            if (vmin > d) vmin = d;
-            if (vmax < d) vmax = d;
+        T lowest = std::numeric_limits<T>::max(), highest = T(0);
+        for (size_t i = 0; i < plane.size(); ++i)
+            if (plane[i] != nothing) { lowest = std::min(lowest, plane[i]); highest = std::max(highest, plane[i]); }
+        const float span = float(highest - lowest);
+        for (size_t i = 0; i < plane.size(); ++i) {
+            int level = 0;
+            if (plane[i] != nothing) {
+                const float part = float(plane[i] - lowest) / span;
+                level = int((nearIsBright ? 1 - part : part) * 255);
+                level = std::max(0, std::min(255, level));
+            }
+            bytes[i] = (uint8_t)level;
         }
-        for (size_t i = 0; i < data.size(); ++i) {
-            if (data[i] == skipv) { out[i] = 0; continue; }
-            float f = float(data[i] - vmin) / float(vmax - vmin);
-            if (invert) f = 1 - f;
-            const int c = int(f * 255);
-            out[i] = c < 0 ? 0 : (c > 255 ? 255 : c);
-        }
-        return vmax;
+        return highest;
     }
 };
 

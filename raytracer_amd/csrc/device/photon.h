@@ -302,88 +302,124 @@ __global__ __launch_bounds__(kBlock) void k_scan_add(uint32_t *__restrict__ out,
 constexpr int kGatherK = RT_GATHER_MAX_PHOTONS;
 constexpr uint32_t kFarIsLow = 0x80000000u, kFarDone = 0x40000000u;
 
-// Heap of one lane: 130 entries of (dist2, node), entry e at heap[e]; entry 0 is unused (dist2[0] lives in a
-// register), entry 129 is padding so that the pair (j, j+1) can always be read with one 16-byte load.
-// A lane's entries are contiguous in global memory (not interleaved with other lanes' as private arrays
-// are): a sift step is one 16-byte load of both children and one 8-byte store.  Entries 1..kHeapLds (the top
-// levels, which every replacement goes through) live in LDS instead, behind the lanes' stacks, as
-// top[entry - 1][thread]: the heaps of the lanes in flight (1 KB each, 400 MB) fit no cache, and the lookup is
-// bound by the memory traffic of its own heap.
-#ifndef RT_HEAP_LDS_ENTRIES
-#define RT_HEAP_LDS_ENTRIES 7 // 0, 1, 3, 7 or 15: whole heap levels
+// A lookup keeps the reference's array of found photons (128 entries of (dist2, photon), a max-heap once it is full):
+// every photon closer than the current search radius sifts through up to seven of its levels.  With the array in
+// global memory (1 KB per lane, no cache holds those of all lanes in flight) the lookup waited for its own heap more
+// than for the photons; all of it in LDS leaves room for too few lookups at a time to hide the latency of the tree.
+// So: the top six levels (entries 1..63), the ones every replacement passes, live in LDS as 4 bytes of dist2 and one
+// byte that names one of 128 places in a table of photon ids; the last level (entries 64..128) and the table live in
+// global memory.  A photon's id is written to the table once, when it is found (a replacement reuses the place of the
+// entry it drives out), and read once, for the sum; the last level costs one 16-byte read at the end of a deep sift.
+// A wave looks photons up for kGatherSlots of its lanes at a time: a lane takes part in round
+// (rank among the wave's lookups) / kGatherSlots with slot rank % kGatherSlots.  Entry e of slot s of wave w lies at
+// dist2[e - 1][w * kGatherSlots + s]: the LDS bank depends on the slot alone, whatever entries the lanes are at.
+#ifndef RT_GATHER_SLOTS
+#define RT_GATHER_SLOTS 32
 #endif
-constexpr uint32_t kHeapLds = RT_HEAP_LDS_ENTRIES;
-static_assert(kHeapLds == 0 || kHeapLds == 1 || kHeapLds == 3 || kHeapLds == 7 || kHeapLds == 15, "whole levels of the heap");
-constexpr uint32_t kHeapStride = 130;
+constexpr uint32_t kGatherSlots = RT_GATHER_SLOTS;
+static_assert(kGatherSlots == 8 || kGatherSlots == 16 || kGatherSlots == 32 || kGatherSlots == 64, "slots per wave: a power of two that keeps the LDS bank a function of the slot");
+constexpr uint32_t kHeapSlotStride = kGatherSlots * (kBlock / 64); // slots of a workgroup
+constexpr int kHeapLdsEntries = 63;                                 // whole levels: 1 + 2 + ... + 32
+constexpr size_t kHeapLdsBytes = (size_t)kHeapLdsEntries * kHeapSlotStride * 5;
+constexpr uint32_t kHeapGlobalEntries = 66; // entries 64..128 and one of padding: pairs are read with one 16-byte load
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 struct LaneHeap {
     typedef RT_GLOBAL_AS u32x2 *GH2;
     typedef RT_GLOBAL_AS u32x4 *GH4;
-    GH2 g;    // entry e at g[e]
-    u32x2 *l; // entry e <= kHeapLds at l[(e - 1) * kStackStride]
-    RT_DEV u32x2 get(int e) const { return (uint32_t)e <= kHeapLds ? l[(uint32_t)(e - 1) * kStackStride] : g[e]; }
+    typedef RT_GLOBAL_AS uint32_t *GI;
+    float *d2;    // entry e <= 63: dist2 at d2[(e - 1) * kHeapSlotStride]
+    uint8_t *tag; //                its place in the id table at tag[(e - 1) * kHeapSlotStride]
+    GH2 g;        // entry e >= 64 at g[e - 64] as (dist2, place)
+    GI ids;       // [128] photon of each place
+    RT_DEV u32x2 get(int e) const
+    {
+        if (e <= kHeapLdsEntries) return u32x2{__float_as_uint(d2[(uint32_t)(e - 1) * kHeapSlotStride]), tag[(uint32_t)(e - 1) * kHeapSlotStride]};
+        return g[e - 64];
+    }
     RT_DEV void put(int e, u32x2 v) const
     {
-        if ((uint32_t)e <= kHeapLds) l[(uint32_t)(e - 1) * kStackStride] = v;
-        else g[e] = v;
+        if (e <= kHeapLdsEntries) { d2[(uint32_t)(e - 1) * kHeapSlotStride] = __uint_as_float(v.x); tag[(uint32_t)(e - 1) * kHeapSlotStride] = (uint8_t)v.y; }
+        else g[e - 64] = v;
     }
-    // entries j and j + 1, j even: both on the same side of the boundary (kHeapLds is odd)
+    // entries j and j + 1, j even: both on the same side of the boundary
     RT_DEV u32x4 pair(int j) const
     {
-        if ((uint32_t)j < kHeapLds) {
-            const u32x2 a = l[(uint32_t)(j - 1) * kStackStride], b = l[(uint32_t)j * kStackStride];
-            return u32x4{a.x, a.y, b.x, b.y};
+        if (j < kHeapLdsEntries) {
+            const uint32_t o = (uint32_t)(j - 1) * kHeapSlotStride;
+            return u32x4{__float_as_uint(d2[o]), tag[o], __float_as_uint(d2[o + kHeapSlotStride]), tag[o + kHeapSlotStride]};
         }
-        return *(GH4)&g[j];
+        return *(GH4)&g[j - 64];
     }
 };
-// lds: the workgroup's dynamic LDS, the lanes' stacks first (S.lds_levels entries per thread)
-RT_DEV LaneHeap lane_heap(const DScene &S, uint32_t *lds)
+// lds: the workgroup's dynamic LDS, the lanes' stacks first (S.lds_levels entries per thread), then the heaps' tops
+RT_DEV LaneHeap lane_heap(const DScene &S, uint32_t *lds, uint32_t slot)
 {
     LaneHeap h;
-    h.g = (LaneHeap::GH2)((u32x2 *)S.gather_heaps + ((size_t)blockIdx.x * kBlock + threadIdx.x) * kHeapStride);
-    h.l = (u32x2 *)lds + (size_t)S.lds_levels * kStackStride + threadIdx.x;
+    const uint32_t in_block = (threadIdx.x >> 6) * kGatherSlots + slot;
+    float *base = (float *)(lds + (size_t)S.lds_levels * kStackStride * 2);
+    h.d2 = base + in_block;
+    h.tag = (uint8_t *)(base + (size_t)kHeapLdsEntries * kHeapSlotStride) + in_block;
+    const size_t in_grid = (size_t)blockIdx.x * kHeapSlotStride + in_block;
+    h.g = (LaneHeap::GH2)((u32x2 *)S.gather_heaps + in_grid * kHeapGlobalEntries);
+    h.ids = (LaneHeap::GI)(S.gather_ids + in_grid * RT_GATHER_MAX_PHOTONS);
     return h;
 }
 
-// The walk's stack (one entry per tree level) on top of a lane's BVH stack storage, turned upside down: a BVH walk
-// is busiest near the bottom of its stack, a kd-tree walk near the top (the levels next to the leaves), so here the
-// *deepest* lds_levels levels are the ones in LDS and the levels next to the root go to the overflow array.
+// The walk's stack (one entry per tree level).  While a wave looks photons up none of its lanes is inside a BVH walk,
+// so the slots share the LDS stack storage of all 64 lanes: 64 / kGatherSlots kd levels per BVH level.  A BVH walk is
+// busiest near the bottom of its stack, a kd-tree walk near the top (the levels next to the leaves), so the *deepest*
+// levels are the ones in LDS and the levels next to the root go to the lane's overflow array if the tree is taller.
 struct KdStack {
     LaneStack st;
-    uint32_t base; // first level kept in LDS = levels that live in the overflow array
-    RT_DEV KdStack(const LaneStack &s, uint32_t ovf_levels) : st(s), base(ovf_levels) {}
+    u32x2 *wave_lds; // level 0 of lane 0 of this wave
+    uint32_t slot;
+    uint32_t capacity; // kd levels the LDS storage holds
+    uint32_t base;     // first level kept in LDS = levels that live in the overflow array
+    RT_DEV KdStack(const LaneStack &s, uint32_t *lds, uint32_t slot_) : st(s), slot(slot_), base(0)
+    {
+        wave_lds = (u32x2 *)lds + (threadIdx.x & ~63u);
+        capacity = s.lds_levels * (64u / kGatherSlots);
+    }
+    RT_DEV void set_height(uint32_t height) { base = height > capacity ? height - capacity : 0u; }
+    RT_DEV u32x2 *at(uint32_t level) const
+    {
+        constexpr uint32_t per = 64u / kGatherSlots;
+        return wave_lds + (level / per) * kStackStride + (level % per) * kGatherSlots + slot;
+    }
     RT_DEV void push(int sp, uint32_t data, float dist) const
     {
         const u32x2 e = {data, __float_as_uint(dist)};
-        if ((uint32_t)sp >= base) st.lds[((uint32_t)sp - base) * kStackStride] = e;
+        if ((uint32_t)sp >= base) *at((uint32_t)sp - base) = e;
         else st.ovf[(size_t)(uint32_t)sp * st.ovf_stride] = e;
     }
     RT_DEV void pop(int sp, uint32_t &data, float &dist) const
     {
         u32x2 e;
-        if ((uint32_t)sp >= base) e = st.lds[((uint32_t)sp - base) * kStackStride];
+        if ((uint32_t)sp >= base) e = *at((uint32_t)sp - base);
         else e = st.ovf[(size_t)(uint32_t)sp * st.ovf_stride];
         data = e.x; dist = __uint_as_float(e.y);
     }
 };
 
 template <bool COUNT>
-RT_DEV V3 photon_irradiance(const rt_photon *tree0, uint32_t n, V3 pos, V3 normal, float radius, LaneStack lane_st,
+RT_DEV V3 photon_irradiance(const rt_photon *tree0, uint32_t n, V3 pos, V3 normal, float radius, KdStack st,
                             const LaneHeap H, uint32_t &visits)
 {
     if (n == 0) return mk(0, 0, 0);
-    const uint32_t height = 32u - (uint32_t)__clz((int)n); // levels of the balanced tree = most stack entries + 1
-    const KdStack st(lane_st, height > lane_st.lds_levels ? height - lane_st.lds_levels : 0u);
+    st.set_height(32u - (uint32_t)__clz((int)n)); // levels of the balanced tree = most stack entries + 1
     const GF4 tree = (GF4)(const void *)tree0 - 2; // node i = tree[2 i], tree[2 i + 1]
     const int half = (int)n / 2 - 1;               // nodes below this index are treated as internal (src/photonmap.h:197,346)
     int found = 0;
     float lim = radius * radius; // dist2[0]
     int sp = 0;
     uint32_t cur = 1;
+    bool going_down = true;
+    // One node per trip, whichever way the lane is going, so that the lanes of a wave stay together: on the way down
+    // an inner node is passed (its far side noted on the stack); a leaf, or a node come back to from below, has its
+    // own photon looked at, and then the walk backs up by one stack entry.
     for (;;) {
-        while ((int)cur < half) { // descend towards the query point
-            const f4 q0 = tree[2 * cur], q1 = tree[2 * cur + 1];
+        const f4 q0 = tree[2 * cur], q1 = tree[2 * cur + 1];
+        if (going_down && (int)cur < half) {
             const uint32_t axis = (__float_as_uint(q1.w) >> 24) & 3u;
             const float split = axis == 0 ? q0.x : (axis == 1 ? q0.y : q0.z);
             const float qa = axis == 0 ? pos.x : (axis == 1 ? pos.y : pos.z);
@@ -393,80 +429,76 @@ RT_DEV V3 photon_irradiance(const rt_photon *tree0, uint32_t n, V3 pos, V3 norma
             ++sp;
             if (COUNT) ++visits;
             cur = high_first ? 2 * cur + 1 : 2 * cur;
+            continue;
         }
-        if (COUNT) ++visits;
-        uint32_t node = cur;
-        bool descend = false;
-        for (;;) {
-            { // the node's own photon (src/photonmap.h:357-413)
-                const f4 q0 = tree[2 * node], q1 = tree[2 * node + 1];
-                const V3 dif = mk(q0.x, q0.y, q0.z) - pos;
-                const float dist2 = len2(dif);
-                if (dist2 < lim && !(dot(mk(q1.x, q1.y, q1.z), normal) >= 0.0f)) {
-                    if (found < kGatherK) {
-                        ++found;
-                        H.put(found, u32x2{__float_as_uint(dist2), node});
-                        if (found == kGatherK) { // build the max-heap
-                            const int half_found = found >> 1;
-                            for (int k = half_found; k >= 1; --k) {
-                                int parent = k;
-                                const u32x2 t = H.get(k);
-                                const float td2 = __uint_as_float(t.x);
-                                while (parent <= half_found) {
-                                    int j = parent + parent;
-                                    const u32x4 c = H.pair(j);
-                                    float dj = __uint_as_float(c.x);
-                                    uint32_t ij = c.y;
-                                    if (j < found && dj < __uint_as_float(c.z)) { ++j; dj = __uint_as_float(c.z); ij = c.w; }
-                                    if (td2 >= dj) break;
-                                    H.put(parent, u32x2{__float_as_uint(dj), ij});
-                                    parent = j;
-                                }
-                                H.put(parent, t);
+        if (COUNT && going_down) ++visits;
+        { // the node's own photon (src/photonmap.h:357-413)
+            const uint32_t node = cur;
+            const V3 dif = mk(q0.x, q0.y, q0.z) - pos;
+            const float dist2 = len2(dif);
+            if (dist2 < lim && !(dot(mk(q1.x, q1.y, q1.z), normal) >= 0.0f)) {
+                if (found < kGatherK) {
+                    H.ids[found] = node;
+                    ++found;
+                    H.put(found, u32x2{__float_as_uint(dist2), (uint32_t)(found - 1)});
+                    if (found == kGatherK) { // build the max-heap
+                        const int half_found = found >> 1;
+                        for (int k = half_found; k >= 1; --k) {
+                            int parent = k;
+                            const u32x2 t = H.get(k);
+                            const float td2 = __uint_as_float(t.x);
+                            while (parent <= half_found) {
+                                int j = parent + parent;
+                                const u32x4 c = H.pair(j);
+                                float dj = __uint_as_float(c.x);
+                                uint32_t ij = c.y;
+                                if (j < found && dj < __uint_as_float(c.z)) { ++j; dj = __uint_as_float(c.z); ij = c.w; }
+                                if (td2 >= dj) break;
+                                H.put(parent, u32x2{__float_as_uint(dj), ij});
+                                parent = j;
                             }
+                            H.put(parent, t);
                         }
-                    } else { // replace the farthest
-                        int parent = 1, j = 2;
-                        float top = dist2; // what ends up in entry 1
-                        while (j <= found) {
-                            const u32x4 c = H.pair(j);
-                            float dj = __uint_as_float(c.x);
-                            uint32_t ij = c.y;
-                            if (j < found && dj < __uint_as_float(c.z)) { ++j; dj = __uint_as_float(c.z); ij = c.w; }
-                            if (dist2 > dj) break;
-                            H.put(parent, u32x2{__float_as_uint(dj), ij});
-                            if (parent == 1) top = dj;
-                            parent = j;
-                            j <<= 1;
-                        }
-                        H.put(parent, u32x2{__float_as_uint(dist2), node});
-                        lim = top;
                     }
+                } else { // replace the farthest; the newcomer takes over its place in the id table
+                    const uint32_t place = H.get(1).y;
+                    H.ids[place] = node;
+                    int parent = 1, j = 2;
+                    float top = dist2; // what ends up in entry 1
+                    while (j <= found) {
+                        const u32x4 c = H.pair(j);
+                        float dj = __uint_as_float(c.x);
+                        uint32_t ij = c.y;
+                        if (j < found && dj < __uint_as_float(c.z)) { ++j; dj = __uint_as_float(c.z); ij = c.w; }
+                        if (dist2 > dj) break;
+                        H.put(parent, u32x2{__float_as_uint(dj), ij});
+                        if (parent == 1) top = dj;
+                        parent = j;
+                        j <<= 1;
+                    }
+                    H.put(parent, u32x2{__float_as_uint(dist2), place});
+                    lim = top;
                 }
             }
-            // back up: the parent's far child if it can still hold something closer, else the parent's own photon
-            bool up = false;
-            if (sp > 0) {
-                uint32_t data; float plane2;
-                st.pop(sp - 1, data, plane2);
-                const uint32_t parent = data & 0x3FFFFFFFu;
-                if (!(data & kFarDone) && plane2 < lim) {
-                    st.push(sp - 1, data | kFarDone, plane2);
-                    cur = (data & kFarIsLow) ? 2 * parent : 2 * parent + 1;
-                    descend = true;
-                } else {
-                    --sp;
-                    node = parent;
-                    up = true;
-                }
-            }
-            if (descend || !up) break;
         }
-        if (!descend) break;
+        // back up: the parent's far child if it can still hold something closer, else the parent's own photon
+        if (sp == 0) break;
+        uint32_t data; float plane2;
+        st.pop(sp - 1, data, plane2);
+        const uint32_t parent = data & 0x3FFFFFFFu;
+        if (!(data & kFarDone) && plane2 < lim) {
+            st.push(sp - 1, data | kFarDone, plane2);
+            cur = (data & kFarIsLow) ? 2 * parent : 2 * parent + 1;
+            going_down = true;
+        } else {
+            --sp;
+            cur = parent;
+            going_down = false;
+        }
     }
     V3 sum = mk(0, 0, 0);
     for (int i = 1; i <= found; ++i) {
-        const uint32_t id = H.get(i).y;
+        const uint32_t id = H.ids[H.get(i).y];
         const f4 q0 = tree[2 * id], q1 = tree[2 * id + 1];
         const uint32_t rgb = __float_as_uint(q1.w);
         const V3 col = mk((float)(rgb & 255u) / 255.0f, (float)((rgb >> 8) & 255u) / 255.0f, (float)((rgb >> 16) & 255u) / 255.0f);
@@ -486,11 +518,18 @@ __global__ __launch_bounds__(kBlock) void k_photon_irradiance(DScene S, const rt
     extern __shared__ uint32_t lds[];
     const LaneStack st = lane_stack(lds, S);
     uint32_t visits = 0, gathers = 0;
-    const LaneHeap heap = lane_heap(S, lds);
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-        const V3 e = photon_irradiance<true>(tree, n_photons, ld3(pos3 + (size_t)i * 3), ld3(nrm3 + (size_t)i * 3), radius, st, heap, visits);
-        out3[(size_t)i * 3] = e.x; out3[(size_t)i * 3 + 1] = e.y; out3[(size_t)i * 3 + 2] = e.z;
-        ++gathers;
+    const uint32_t lane = threadIdx.x & 63u, slot = lane % kGatherSlots;
+    const KdStack kd(st, lds, slot);
+    const LaneHeap heap = lane_heap(S, lds, slot);
+    for (int i0 = blockIdx.x * kBlock; i0 < n; i0 += gridDim.x * kBlock) {
+        const int i = i0 + (int)threadIdx.x;
+        for (uint32_t round = 0; round < 64u / kGatherSlots; ++round) { // neighbouring queries together
+            if (i < n && lane / kGatherSlots == round) {
+                const V3 e = photon_irradiance<true>(tree, n_photons, ld3(pos3 + (size_t)i * 3), ld3(nrm3 + (size_t)i * 3), radius, kd, heap, visits);
+                out3[(size_t)i * 3] = e.x; out3[(size_t)i * 3 + 1] = e.y; out3[(size_t)i * 3 + 2] = e.z;
+                ++gathers;
+            }
+        }
     }
     const uint64_t g = wave_sum(gathers), v = wave_sum(visits);
     if ((threadIdx.x & 63) == 0) {

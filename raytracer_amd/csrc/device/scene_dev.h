@@ -86,12 +86,13 @@ struct DScene {
     float environment[3]; // what a secondary ray of the Whitted-style shader sees when it leaves the scene
     int32_t stack_levels; // BVH stack entries a lane may need (deepest mesh + 2), 0 without meshes
     int32_t lds_levels;   // of which in LDS; the rest in stack_overflow
+    uint2 *gather_heaps;   // [photon-lookup slots of the largest grid][66]: last level of the slots' heaps of nearest photons
+    uint32_t *gather_ids;  // [slots][128]: the photons found
     uint2 *stack_overflow; // [(stack_levels - lds_levels)][threads of the largest grid]
     const rt_photon *pmap[2]; // balanced photon maps (global, caustics), node 1 first; null when not built
     uint32_t pmap_n[2];
     const DTexture *textures;
     int32_t background_texture, environment_texture; // 1 + index, 0 = none
-    uint2 *gather_heaps; // [threads of the largest grid][130]: the lanes' heaps of nearest photons
     // two words of pinned host memory, read and written in place (system scope):
     const uint32_t *cancel;       // non-zero: hand out no more work (rt_cancel); read by the persistent kernels when they draw from their queues
     unsigned long long *progress; // items of the running lock-step kernel's queue handed out so far (rt_progress)

@@ -46,16 +46,15 @@ struct WFrame {
 };
 
 
-// Blinn-Phong term of one light (p12 materials.cpp:33-47)
-RT_DEV void whitted_light_term(WFrame &f, const rt_material &m, V3 lightIntensity, V3 lightDir)
+// Blinn-Phong term of one light (p12 materials.cpp:33-47): Lambert and the normalised Blinn lobe, both weighted by
+// the cosine between the normal and the light
+RT_DEV void whitted_light_term(WFrame &f, const rt_material &m, V3 radiance, V3 to_light)
 {
-    const V3 normal = f.n;
-    const float geometryTerm = std_max(0.0f, dot(normal, lightDir));
-    f.final = f.final + ((f.kd * kInvPiF) * lightIntensity) * geometryTerm;
-    const V3 halfway = normalize(f.v + lightDir);
-    const float blinnTerm = std_max(0.0f, dot(normal, halfway));
-    const float k = (float)((double)(m.glossiness + 2.0f) / kEightPi);
-    f.final = f.final + (((ld3(m.specular) * k) * powf(blinnTerm, m.glossiness)) * lightIntensity) * geometryTerm;
+    const float cos_l = std_max(0.0f, dot(f.n, to_light));
+    f.final = f.final + ((f.kd * kInvPiF) * radiance) * cos_l;
+    const float cos_h = std_max(0.0f, dot(f.n, normalize(f.v + to_light)));
+    const float lobe_norm = (float)((double)(m.glossiness + 2.0f) / kEightPi);
+    f.final = f.final + (((ld3(m.specular) * lobe_norm) * powf(cos_h, m.glossiness)) * radiance) * cos_l;
 }
 
 // Shadow ray number i of the soft-shadow fan towards a spherical light (p12 lights.h:76-97):
@@ -167,18 +166,24 @@ __global__ __launch_bounds__(kBlock, RT_WHITTED_MIN_WAVES) void k_whitted(DScene
         // then gather together.
         const uint64_t parked = __ballot(state == W_GATHER);
         if (parked != 0 && (__popcll(parked) >= kGatherQuorum || !__any(state == W_TRACE || state == W_SHADOW))) {
-            if (state == W_GATHER) {
-                const V3 kd = cur.kd * kInvPiF;
-                const LaneHeap heap = lane_heap(S, lds);
-                if (pm & (RT_PM_DIRECT | RT_PM_INDIRECT)) {
-                    cur.final = cur.final + kd * photon_irradiance<COUNT>(S.pmap[0], S.pmap_n[0], cur.p, cur.n, F.gather_radius, st, heap, visits);
-                    ++gathers;
+            // kGatherSlots lanes at a time: that many arrays of found photons fit the wave's share of LDS
+            const uint32_t rank = (uint32_t)__popcll(parked & ((1ull << lane) - 1ull));
+            const uint32_t n_parked = (uint32_t)__popcll(parked);
+            for (uint32_t first = 0; first < n_parked; first += kGatherSlots) {
+                if (state == W_GATHER && rank >= first && rank < first + kGatherSlots) {
+                    const V3 kd = cur.kd * kInvPiF;
+                    const KdStack kst(st, lds, rank - first);
+                    const LaneHeap heap = lane_heap(S, lds, rank - first);
+                    if (pm & (RT_PM_DIRECT | RT_PM_INDIRECT)) {
+                        cur.final = cur.final + kd * photon_irradiance<COUNT>(S.pmap[0], S.pmap_n[0], cur.p, cur.n, F.gather_radius, kst, heap, visits);
+                        ++gathers;
+                    }
+                    if (pm & RT_PM_CAUSTICS) {
+                        cur.final = cur.final + kd * photon_irradiance<COUNT>(S.pmap[1], S.pmap_n[1], cur.p, cur.n, F.gather_radius, kst, heap, visits);
+                        ++gathers;
+                    }
+                    state = W_CTRL;
                 }
-                if (pm & RT_PM_CAUSTICS) {
-                    cur.final = cur.final + kd * photon_irradiance<COUNT>(S.pmap[1], S.pmap_n[1], cur.p, cur.n, F.gather_radius, st, heap, visits);
-                    ++gathers;
-                }
-                state = W_CTRL;
             }
         }
 

@@ -241,8 +241,8 @@ const void *wf_trace_kernel(bool counting, int ray_levels)
 }
 
 size_t stack_lds_bytes(const DScene &S) { return (size_t)S.lds_levels * kBlock * 8; }
-// kernels that look photons up keep the top of every lane's heap behind the stacks
-size_t gather_lds_bytes(const DScene &S) { return stack_lds_bytes(S) + (size_t)kHeapLds * kBlock * 8; }
+// kernels that look photons up keep the arrays of found photons of kGatherSlots lanes per wave behind the stacks
+size_t gather_lds_bytes(const DScene &S) { return stack_lds_bytes(S) + kHeapLdsBytes; }
 
 } // namespace
 
@@ -1291,19 +1291,22 @@ int ensure_stack_levels(rt_ctx *ctx, int levels)
     if (levels <= S.stack_levels) return RT_OK;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     S.stack_levels = levels;
-    // four workgroups of the lookup kernels share a CU's 160 KiB: 20 eight-byte entries per thread, the heap tops included
-    S.lds_levels = std::min(S.stack_levels, std::min(ctx->lds_levels_max, 19 - (int)kHeapLds));
+    // the lookup kernels put the arrays of found photons behind the stacks: leave room for three workgroups per CU
+    const int room = (int)((160 * 1024 / 3 - 512 - (int)kHeapLdsBytes) / (kBlock * 8));
+    S.lds_levels = std::min(S.stack_levels, std::min(ctx->lds_levels_max, std::max(room, 2)));
     const size_t ovf_levels = (size_t)(S.stack_levels - S.lds_levels);
     HIP_TRY(ctx, ctx->d_stack_ovf.reserve(std::max<size_t>(1, ovf_levels) * ctx->ovf_threads * sizeof(uint2)));
     S.stack_overflow = ctx->d_stack_ovf.as<uint2>();
     return RT_OK;
 }
 
-// one heap of nearest photons per thread of the largest grid (545 MB on 256 CUs), allocated with the first map
+// what a photon lookup keeps outside LDS, per slot of the largest grid: the last level of its heap and the ids of the photons found
 int ensure_gather_heaps(rt_ctx *ctx)
 {
-    HIP_TRY(ctx, ctx->d_gather_heaps.reserve(ctx->ovf_threads * kHeapStride * sizeof(uint2)));
+    const size_t slots = ctx->ovf_threads / kBlock * kHeapSlotStride;
+    HIP_TRY(ctx, ctx->d_gather_heaps.reserve(slots * (kHeapGlobalEntries * sizeof(uint2) + RT_GATHER_MAX_PHOTONS * sizeof(uint32_t))));
     ctx->scene.gather_heaps = ctx->d_gather_heaps.as<uint2>();
+    ctx->scene.gather_ids = (uint32_t *)(ctx->scene.gather_heaps + slots * kHeapGlobalEntries);
     return RT_OK;
 }
 
@@ -1492,10 +1495,10 @@ int rt_photons_build(rt_ctx *ctx, int which, const rt_photon *photons, uint32_t 
     HIP_TRY(ctx, hipEventElapsedTime(&build_ms, ctx->evk0, ctx->evk1));
     ctx->counters = rt_counters{};
     ctx->counters.kernel_ms = build_ms;
+    if (int rc = ensure_gather_heaps(ctx)) return rc;
     int levels = 1;
     while ((1u << levels) <= n) ++levels; // tree height
     if (int rc = ensure_stack_levels(ctx, levels + 1)) return rc;
-    if (int rc = ensure_gather_heaps(ctx)) return rc;
     ctx->pmap_n[which] = n;
     return RT_OK;
 }

@@ -1,10 +1,11 @@
 #!/bin/bash
-# tests/prof_sq.sh OUTNAME [variant]: three SQ counter passes of one bench frame (RT_PIPELINE is inherited)
+# tests/prof_sq.sh OUTNAME [variant]: three SQ counter passes of one bench frame (RT_PIPELINE is inherited),
+# or of the program PROF_CMD names
 set -e
 OUT=$PWD/gpurun_out/$1; V=${2:-base}
 if [ "$V" != base ]; then export RT_LIB=$PWD/raytracer_amd/variants/librt_$V.so; fi
 export TMPDIR=/tmp
-B="python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline $BENCH_ARGS"
+B="${PROF_CMD:-python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline $BENCH_ARGS}"
 mkdir -p $OUT
 timeout -s KILL 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES --output-format csv -d $OUT/a -o p -- $B > $OUT/a.log 2>&1
 timeout -s KILL 200 rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM_RD --output-format csv -d $OUT/b -o p -- $B > $OUT/b.log 2>&1
