@@ -239,11 +239,14 @@ template <bool COUNT, int LEVELS, class IO> struct RayWalker {
 
     // ================= BVH steps (TriObj.cpp:30-122 / 149-226) =================
     // The node to visit next is kept in a register (cur): of two children that are hit only the
-    // farther one goes to the stack, the nearer one is visited in the next trip - exactly the
-    // order of the reference, which pushes both and pops the nearer one at once (its entry
-    // distance was just tested against the current closest hit, so the pop-time test of the
-    // reference cannot fail for it and is not repeated).  The stack is read only when a visit
-    // leaves nothing to go on with.
+    // farther one goes to the stack, the nearer one is visited in the next trip.  In the binary
+    // walk that is exactly the order of the reference, which pushes both and pops the nearer one
+    // at once (its entry distance was just tested against the current closest hit, so the
+    // pop-time test of the reference cannot fail for it and is not repeated).  The four-wide walk
+    // (kWide) visits the children of two levels in distance order instead: same closest hit, but
+    // pruned against a different "best so far", so t can differ in the last bit now and then -
+    // which is why the depth / id planes and the query entry points use the binary walk.  The
+    // stack is read only when a visit leaves nothing to go on with.
     // A lane whose next node is a leaf parks there: triangle tests are long and only a few
     // lanes reach a leaf in any one trip, so they run for many lanes at once.
     while (__any(in_bvh)) {
