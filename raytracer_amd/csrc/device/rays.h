@@ -112,6 +112,8 @@ template <bool COUNT, int LEVELS, class IO> struct RayWalker {
     static constexpr bool kWide = IO::kWide && !COUNT;
     bool active = false, any_hit = false, in_bvh = false;
     bool unoccluded = false;             // a finished shadow ray whose answer the IO has not been told yet (retire())
+    bool finished = false;               // a closest-hit ray through with every object: the lights and the answer are due (finish_closest())
+    int mesh_node = 0;                   // scene node of the mesh the ray is in
     uint32_t tag = 0;                    // the list entry as the IO names it
     Ray wray{mk(0, 0, 0), mk(0, 0, 1)};  // world space
     float t_max = 0.0f;
@@ -129,7 +131,7 @@ template <bool COUNT, int LEVELS, class IO> struct RayWalker {
         wray.p = mk(o.x, o.y, o.z); wray.d = mk(d.x, d.y, d.z);
         any_hit = shadow; t_max = tmax;
         if (any_hit) ++pt.shadow; else ++pt.closest;
-        node_i = 0; in_bvh = false; active = true;
+        node_i = 0; in_bvh = false; active = true; finished = false;
         best_t = FLT_MAX; best_node = -1; best_front = 1; best_face = 0; best_u = 0; best_v = 0;
     }
     // A shadow ray's answer is handed over when the lane takes its next ray (retire(), called by the refill step): what
@@ -140,6 +142,40 @@ template <bool COUNT, int LEVELS, class IO> struct RayWalker {
         else io.put_shadow(tag, occluded);
         active = false;
     }
+
+    // A closest-hit ray that is through with the objects: the spherical lights last (main.cpp:52-70, lights.h:129-156),
+    // front side only, then the answer.  Called by the refill step, where the lane takes its next ray.
+    RT_DEV void finish_closest(const DScene &S, const IO &io)
+    {
+        for (int l = 0; l < S.n_lights; ++l) {
+            const rt_light &L = S.lights[l];
+            if (L.type != RT_LIGHT_POINT) continue;
+            Ray r;
+            r.p = wray.p - ld3(L.position);
+            r.d = wray.d;
+            if (L.size != 1.0f) { r.p = r.p / L.size; r.d = r.d / L.size; } // x / 1 is x
+            const float a = dot(r.d, r.d);
+            const float b = 2 * dot(r.d, r.p);
+            const float c = dot(r.p, r.p) - 1.0f;
+            const float disc = b * b - 4 * a * c;
+            if (disc < 0.0f) continue;
+            const float s = fsqrt(disc);
+            const float inv2a = 1.0f / (2.0f * a);
+            const float t1 = (-b - s) * inv2a;
+            if (t1 <= 0.0f) continue;
+            if (t1 < best_t) { best_t = t1; best_node = -2 - l; best_front = 1; break; }
+        }
+        io.put_closest(tag, best_t, best_node, best_face, best_front, best_u, best_v);
+        finished = false;
+    }
+    // A ray that enters a mesh does not leave the scene pass for it: it notes the entry, goes on through the remaining
+    // objects (spheres and planes are a handful of instructions each, and a shadow ray one of them stops never walks
+    // the mesh) and starts the walk when the pass is over, so that a ray of a scene with one mesh takes part in one
+    // pass, not two.  The reference takes the objects in list order and keeps the first of two hits at exactly the same
+    // distance; the mesh's hit is therefore folded in with its place in the list as the tie-break.  A second mesh met
+    // while one is noted ends the lane's pass there.  (Not in the counting variant: a shadow ray stopped by a later
+    // sphere would skip box and triangle tests the reference makes.)
+    static constexpr bool kDeferMesh = !COUNT;
 
     // The scene pass, if enough lanes wait for it, then BVH steps while enough lanes are inside a mesh.
     // Called by the whole wave; every call makes progress if any lane has a ray.
@@ -163,12 +199,14 @@ template <bool COUNT, int LEVELS, class IO> struct RayWalker {
         // business with costs the wave nothing but this test.  The reference tests every object (it keeps the boxes,
         // src/scene.h:434-444, but never looks at them).
         const V3 winv = cull_inverse(wray.d);
+        bool noted = false;   // a mesh entry waits for the end of the pass
+        bool stopped = false; // ... and the lane has met a second mesh
         for (int n = 0; n < S.n_nodes; ++n) {
             const TNode &nd = S.tnodes[n];
             const uint32_t meta = nd.meta;
             const int prim = (int)(meta & 0xFFu), d = (int)((meta >> 8) & 0xFFu);
             const bool has_children = (meta >> 16) != 0;
-            bool here = mine && active && !in_bvh; // still in the pass
+            bool here = mine && active && !in_bvh && !stopped; // still in the pass
             // (the counting variant takes every object, as the reference does: its box and triangle tests are the reference's)
             const bool wanted = here && n >= first && prim != RT_PRIM_NONE && (COUNT || reaches_box(nd.wbox, wray.p, winv, any_hit ? t_max : best_t));
             if (here && n >= first && !wanted) node_i = n + 1; // nothing to do at this node
@@ -185,7 +223,7 @@ template <bool COUNT, int LEVELS, class IO> struct RayWalker {
                     if (prim == RT_PRIM_SPHERE || prim == RT_PRIM_PLANE) {
                         if (any_hit) {
                             const bool occ = prim == RT_PRIM_SPHERE ? sphere_shadow(l, t_max) : plane_shadow(l, t_max);
-                            if (occ) { shadow_done(io, true); advance = false; }
+                            if (occ) { shadow_done(io, true); advance = false; noted = false; }
                         } else {
                             float t = 0; int front = 1;
                             const bool ok = prim == RT_PRIM_SPHERE ? sphere_t(l, t, front) : plane_t(l, t, front);
@@ -198,41 +236,24 @@ template <bool COUNT, int LEVELS, class IO> struct RayWalker {
                         const f4 r0 = {nd.box[0], nd.box[1], nd.box[2], nd.box[3]}, r1 = {nd.box[4], nd.box[5], 0.0f, 0.0f};
                         float dist;
                         tl.boxes(1);
-                        if (bvh_box(ex, l.p, iv, lim, r0, r1, dist)) {
+                        if (!bvh_box(ex, l.p, iv, lim, r0, r1, dist)) {}
+                        else if (noted) { stopped = true; advance = false; } // one walk at a time: come back to this node after it
+                        else {
                             lr = l; inv = iv; exact = ex; t_limit = lim; m_hit = false;
                             cur = kWide ? nd.root4 : nd.root; // the root is the node to visit next; the stack is empty
-                            sp = 0; in_bvh = true; advance = false;
+                            sp = 0; mesh_node = n;
+                            if (kDeferMesh) noted = true;
+                            else { in_bvh = true; advance = false; }
                         }
                     }
                     if (advance) node_i = n + 1;
                 }
             }
         }
-        if (mine && active && !in_bvh) { // ran off the end of the node list
+        if (mine && active && noted) in_bvh = true; // the walk of the mesh noted on the way
+        else if (mine && active && !in_bvh) { // ran off the end of the node list
             if (any_hit) shadow_done(io, false); // nothing in the way
-            else {
-                // closest ray: the spherical lights last (main.cpp:52-70, lights.h:129-156), front side only
-                for (int l = 0; l < S.n_lights; ++l) {
-                    const rt_light &L = S.lights[l];
-                    if (L.type != RT_LIGHT_POINT) continue;
-                    Ray r;
-                    r.p = wray.p - ld3(L.position);
-                    r.d = wray.d;
-                    if (L.size != 1.0f) { r.p = r.p / L.size; r.d = r.d / L.size; } // x / 1 is x
-                    const float a = dot(r.d, r.d);
-                    const float b = 2 * dot(r.d, r.p);
-                    const float c = dot(r.p, r.p) - 1.0f;
-                    const float disc = b * b - 4 * a * c;
-                    if (disc < 0.0f) continue;
-                    const float s = fsqrt(disc);
-                    const float inv2a = 1.0f / (2.0f * a);
-                    const float t1 = (-b - s) * inv2a;
-                    if (t1 <= 0.0f) continue;
-                    if (t1 < best_t) { best_t = t1; best_node = -2 - l; best_front = 1; break; }
-                }
-                io.put_closest(tag, best_t, best_node, best_face, best_front, best_u, best_v);
-                active = false;
-            }
+            else { finished = true; active = false; }
         }
         pt.ran(1, stepping);
     }
@@ -335,14 +356,17 @@ template <bool COUNT, int LEVELS, class IO> struct RayWalker {
         }
         if (in_bvh && !at_leaf && cur == kNoNode && sp == 0) { // mesh done: fold its result into the ray's (main.cpp:38-48 / 80-85)
             in_bvh = false;
+            if (!kDeferMesh) node_i = mesh_node + 1; // (deferred entry: the pass has moved node_i on already)
+            const bool through = node_i >= S.n_nodes;
             if (any_hit) {
                 if (m_hit) shadow_done(io, true);
-                else ++node_i;
+                else if (through) shadow_done(io, false);
             } else {
-                if (m_hit && t_limit < best_t) {
-                    best_t = t_limit; best_node = node_i; best_front = m_det > 0.0f; best_face = m_face; best_u = m_u; best_v = m_v;
+                // the nearer hit wins, of two equally near ones the object that comes first in the list
+                if (m_hit && (t_limit < best_t || (kDeferMesh && t_limit == best_t && best_node > mesh_node))) {
+                    best_t = t_limit; best_node = mesh_node; best_front = m_det > 0.0f; best_face = m_face; best_u = m_u; best_v = m_v;
                 }
-                ++node_i;
+                if (through) { finished = true; active = false; }
             }
         }
         if ((uint32_t)__popcll(__ballot(in_bvh)) < (uint32_t)RT_RAYS_BVH_MIN_LANES) break;
@@ -396,6 +420,7 @@ __global__ __launch_bounds__(kBlock, RT_RAYS_MIN_WAVES) void k_rays(DScene S, IO
             typename IO::Pending pend; // what the lane's finished shadow ray still has to hand over: its loads go out first
             const bool owes = IO::kDeferShadow && !w.active && w.unoccluded;
             if (owes) io.begin_put_shadow(w.tag, pend);
+            if (!w.active && w.finished) w.finish_closest(S, io);
             if (taking) {
                 const uint32_t e = chunk_next + rank;
                 float4 o, d; bool shadow; float tmax; uint32_t tg;
@@ -414,6 +439,7 @@ __global__ __launch_bounds__(kBlock, RT_RAYS_MIN_WAVES) void k_rays(DScene S, IO
         w.phases(S, io, st, pt, tl);
     }
     if (IO::kDeferShadow && w.unoccluded) { typename IO::Pending pend; io.begin_put_shadow(w.tag, pend); io.end_put_shadow(w.tag, pend); }
+    if (w.finished) w.finish_closest(S, io);
     flush_counters<COUNT>(ctr, pt, tl, 0);
 }
 
