@@ -95,6 +95,12 @@ struct BriefIO {
 #define RT_RAYS_REFILL_MIN_LANES 24 // fetch new rays once this many lanes are idle
 #endif
 
+// Records of the four-wide BVH kept in LDS by the ray-list kernel: the top levels of the scene's largest mesh, which
+// every ray of it passes (85 = three full levels; 0 builds the cache out)
+#ifndef RT_TOP4_RECORDS
+#define RT_TOP4_RECORDS 0
+#endif
+constexpr int kTop4Records = RT_TOP4_RECORDS;
 constexpr uint32_t kRayChunk = 256; // rays a wave reserves per queue atomic unless the launch says otherwise
 constexpr uint32_t kNoNode = 0x7FFFFFFFu; // not a data word: an inner node's first child index is far smaller
 
@@ -179,7 +185,7 @@ template <bool COUNT, int LEVELS, class IO> struct RayWalker {
 
     // The scene pass, if enough lanes wait for it, then BVH steps while enough lanes are inside a mesh.
     // Called by the whole wave; every call makes progress if any lane has a ray.
-    RT_DEV void phases(const DScene &S, const IO &io, const LaneStack &st, PathTally &pt, Tally<COUNT> &tl)
+    RT_DEV void phases(const DScene &S, const IO &io, const LaneStack &st, const f4 *top4, PathTally &pt, Tally<COUNT> &tl)
     {
         const float epsilon = 1e-6f;
         const GF4 bvh = (GF4)S.bvh_pool, tris = (GF4)S.tri_pool;
@@ -283,8 +289,15 @@ template <bool COUNT, int LEVELS, class IO> struct RayWalker {
             if (cur != kNoNode) {
                 if (cur & kLeafBit) { at_leaf = true; leaf_data = cur; leaf_i = 0; cur = kNoNode; }
                 else if (kWide) {
-                    const GF4 rec = (GF4)S.bvh4_pool + (size_t)cur * 8;
-                    const f4 a0 = rec[0], a1 = rec[1], b0 = rec[2], b1 = rec[3], c0 = rec[4], c1 = rec[5], e0 = rec[6], e1 = rec[7];
+                    f4 a0, a1, b0, b1, c0, c1, e0, e1;
+                    const uint32_t above = cur - S.top4_base; // place among the records kept in LDS, if it is one
+                    if (kTop4Records > 0 && above < S.top4_count) {
+                        const f4 *rec = top4 + above * 8;
+                        a0 = rec[0]; a1 = rec[1]; b0 = rec[2]; b1 = rec[3]; c0 = rec[4]; c1 = rec[5]; e0 = rec[6]; e1 = rec[7];
+                    } else {
+                        const GF4 rec = (GF4)S.bvh4_pool + (size_t)cur * 8;
+                        a0 = rec[0]; a1 = rec[1]; b0 = rec[2]; b1 = rec[3]; c0 = rec[4]; c1 = rec[5]; e0 = rec[6]; e1 = rec[7];
+                    }
                     float d0, d1, d2, d3;
                     const bool h0 = bvh_box(exact, lr.p, inv, t_limit, a0, a1, d0) && d0 < t_limit;
                     const bool h1 = bvh_box(exact, lr.p, inv, t_limit, b0, b1, d1) && d1 < t_limit;
@@ -387,6 +400,13 @@ __global__ __launch_bounds__(kBlock, RT_RAYS_MIN_WAVES) void k_rays(DScene S, IO
     PathTally pt;
     Tally<COUNT> tl;
     RayWalker<COUNT, LEVELS, IO> w;
+    // the top of the wide BVH behind the stacks
+    f4 *top4 = (f4 *)(lds + (size_t)S.lds_levels * kStackStride * 2);
+    if (kTop4Records > 0 && RayWalker<COUNT, LEVELS, IO>::kWide && S.top4_count != 0) {
+        const GF4 src = (GF4)S.bvh4_pool + (size_t)S.top4_base * 8;
+        for (uint32_t i = threadIdx.x; i < S.top4_count * 8; i += kBlock) top4[i] = src[i];
+        __syncthreads();
+    }
 
     // wave-uniform window of the ray list
     uint32_t chunk_next = 0, chunk_end = 0;
@@ -436,7 +456,7 @@ __global__ __launch_bounds__(kBlock, RT_RAYS_MIN_WAVES) void k_rays(DScene S, IO
             if (exhausted) break; // every wave gets here: the queue word only grows
             continue;
         }
-        w.phases(S, io, st, pt, tl);
+        w.phases(S, io, st, top4, pt, tl);
     }
     if (IO::kDeferShadow && w.unoccluded) { typename IO::Pending pend; io.begin_put_shadow(w.tag, pend); io.end_put_shadow(w.tag, pend); }
     if (w.finished) w.finish_closest(S, io);

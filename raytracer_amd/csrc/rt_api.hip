@@ -287,7 +287,8 @@ static int render_wavefront(rt_ctx *ctx, const DFrame &F, const int32_t *act, ui
 
     const void *fn = wf_trace_kernel(ctx->counting, ctx->ray_levels);
     int per_cu = 1;
-    HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kBlock, lds));
+    const size_t lds_rays = lds + (ctx->counting ? 0 : (size_t)ctx->scene.top4_count * 128); // the top of the wide BVH behind the stacks
+    HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kBlock, lds_rays));
     per_cu = std::max(1, std::min(per_cu, 8));
     DScene a_scene = ctx->scene;
     DCounters *a_ctr = ctx->d_counters.as<DCounters>();
@@ -311,7 +312,7 @@ static int render_wavefront(rt_ctx *ctx, const DFrame &F, const int32_t *act, ui
             HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue.p, 0, kQueueBytes, s));
             const bool timed = launch < rt_ctx::kMaxRayLaunches;
             if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ray_ev[2 * launch], s));
-            HIP_TRY(ctx, hipLaunchKernel(fn, grid, dim3(kBlock), targs, lds, s));
+            HIP_TRY(ctx, hipLaunchKernel(fn, grid, dim3(kBlock), targs, lds_rays, s));
             if (timed) { HIP_TRY(ctx, hipEventRecord(ctx->ray_ev[2 * launch + 1], s)); ++launch; }
         }
         if (finishing) n_ext = held_ext;
@@ -554,6 +555,7 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc)
     std::vector<rt_bvh_node> roots(sc->n_meshes);
     std::vector<float4> bvh4; // records of eight float4
     std::vector<uint32_t> root4(sc->n_meshes, 0);
+    size_t top4_mesh_records = 0; uint32_t top4_base = 0, top4_count = 0;
     for (uint32_t mi = 0; mi < sc->n_meshes; ++mi) {
         const rt_mesh &m = sc->meshes[mi];
         for (size_t k = 0; k < (size_t)m.nf * 3; ++k)
@@ -607,10 +609,13 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc)
                 todo.push_back({id, rec});
                 return (uint32_t)rec;
             };
+            const size_t first_rec = bvh4.size() / 8;
             root4[mi] = record_of(1);
-            while (!todo.empty()) {
-                const auto [id, rec] = todo.back();
-                todo.pop_back();
+            size_t head = 0; // the first kTop4Records records of a mesh are its top levels in breadth-first order (first in, first out), the rest depth-first
+            while (head < todo.size()) {
+                const bool breadth = bvh4.size() / 8 - first_rec < (size_t)kTop4Records;
+                const auto [id, rec] = breadth ? todo[head] : todo.back();
+                if (breadth) ++head; else todo.pop_back();
                 const uint32_t c = m.bvh_nodes[id].data & 0x7FFFFFFFu;
                 uint32_t slots[4], ns = 0;
                 for (uint32_t ch = c; ch < c + 2; ++ch) {
@@ -630,6 +635,12 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc)
                 }
             }
             if (bvh4.size() / 8 >= ((size_t)1 << 31)) return ctx->fail(RT_ERR_UNSUPPORTED, "scene has too many BVH nodes");
+            const size_t n_rec = bvh4.size() / 8 - first_rec;
+            if (kTop4Records > 0 && !is_leaf(1) && n_rec > top4_mesh_records) { // the largest mesh's top levels go to LDS
+                top4_mesh_records = n_rec;
+                top4_base = (uint32_t)first_rec;
+                top4_count = (uint32_t)std::min<size_t>(n_rec, (size_t)kTop4Records);
+            }
         }
         max_mesh_depth = std::max(max_mesh_depth, (int)depth);
         DMesh &d = dmeshes[mi];
@@ -737,6 +748,7 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc)
     HIP_TRY(ctx, hipMemcpy(ctx->d_tnodes.p, tnodes.data(), sizeof(TNode) * nn, hipMemcpyHostToDevice));
     S.tnodes = ctx->d_tnodes.as<TNode>();
     S.bvh_pool = d_bvh_pool; S.tri_pool = d_tri_pool; S.bvh4_pool = d_bvh4_pool;
+    S.top4_base = top4_base; S.top4_count = top4_count;
     S.cancel = (const uint32_t *)&ctx->host_words[0];
     S.progress = &ctx->host_words[1];
     HIP_TRY(ctx, ctx->d_meshes.reserve(sizeof(DMesh) * std::max<size_t>(1, dmeshes.size())));
