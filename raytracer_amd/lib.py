@@ -39,6 +39,12 @@ def load():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing - build it with `python -c 'import __graft_entry__ as g; g.build()'`")
+    # PyTorch carries its own copy of the HIP runtime; of two copies in one process only the one loaded first sees the
+    # GPU.  Where torch is installed it goes first, so that a later `import torch` (frame gather, benchmarks) still works.
+    import importlib.util
+    import sys
+    if "torch" not in sys.modules and not os.environ.get("RT_NO_TORCH") and importlib.util.find_spec("torch") is not None:
+        import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     L.rt_abi_version.restype = C.c_int
