@@ -83,13 +83,13 @@ struct BriefIO {
 #endif
 
 #ifndef RT_RAYS_BVH_MIN_LANES
-#define RT_RAYS_BVH_MIN_LANES 32 // keep taking BVH steps while at least this many lanes are inside a mesh
+#define RT_RAYS_BVH_MIN_LANES 24 // keep taking BVH steps while at least this many lanes are inside a mesh
 #endif
 #ifndef RT_RAYS_LEAF_MIN_LANES
 #define RT_RAYS_LEAF_MIN_LANES 16 // run triangle tests once this many lanes are parked at a leaf
 #endif
 #ifndef RT_RAYS_SCENE_MIN_LANES
-#define RT_RAYS_SCENE_MIN_LANES 16 // run a pass over the scene nodes once this many lanes wait outside a mesh
+#define RT_RAYS_SCENE_MIN_LANES 12 // run a pass over the scene nodes once this many lanes wait outside a mesh
 #endif
 #ifndef RT_RAYS_REFILL_MIN_LANES
 #define RT_RAYS_REFILL_MIN_LANES 24 // fetch new rays once this many lanes are idle
