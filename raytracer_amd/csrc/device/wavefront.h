@@ -163,6 +163,7 @@ __global__ __launch_bounds__(kBlock) void k_wf_finish(DScene S, DFrame F, int k0
 
 constexpr uint32_t kShadeRounds = 8;                      // paths per lane and list reservation
 constexpr uint32_t kShadeChunk = kShadeRounds * kBlock;   // paths per workgroup and list reservation
+constexpr uint32_t kShadeBins = 64;                       // nothing, lights, then the scene's nodes (the last bin takes the rest)
 
 // position of this lane's entry in the workgroup's LDS list: one LDS atomic per wave
 RT_DEV uint32_t lds_append(uint32_t *count, bool want)
@@ -186,20 +187,59 @@ __global__ __launch_bounds__(kBlock) void k_wf_shade(DScene S, DFrame F, const i
                                                      uint32_t *counts, FramePlanes out)
 {
     __shared__ uint32_t s_ext[kShadeChunk], s_sh[kShadeChunk];
+    __shared__ uint32_t s_order[kShadeChunk]; // the chunk's paths, those that hit the same thing next to each other
+    __shared__ uint32_t s_bin[kShadeBins];
     __shared__ uint32_t s_n[2], s_base[2];
     const rt_light &light = S.lights[0];
     const uint32_t n_chunks = (n_in + kShadeChunk - 1) / kShadeChunk;
     for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
     if (threadIdx.x < 2) s_n[threadIdx.x] = 0;
+    if (threadIdx.x < kShadeBins) s_bin[threadIdx.x] = 0;
+    __syncthreads();
+    // What a path does here depends on what it hit (nothing, a light, a sphere, a plane, a mesh; which material), and
+    // after the first bounce neighbouring list entries hit unrelated things.  The chunk's paths are therefore dealt
+    // to the lanes ordered by the object they hit (a counting sort in LDS): a wave then runs one kind of shading,
+    // not all of them.  Every path's arithmetic is its own, so the order changes no result.
+    const uint32_t chunk_first = chunk * kShadeChunk;
+    const uint32_t chunk_n = n_in - chunk_first < kShadeChunk ? n_in - chunk_first : kShadeChunk;
+    uint32_t my_slot[kShadeRounds], my_key[kShadeRounds], my_rank[kShadeRounds];
+#pragma unroll
+    for (uint32_t r = 0; r < kShadeRounds; ++r) {
+        const uint32_t i = r * kBlock + threadIdx.x;
+        my_slot[r] = i < chunk_n ? (FIRST ? chunk_first + i : queue_in[chunk_first + i]) : 0u;
+    }
+#pragma unroll
+    for (uint32_t r = 0; r < kShadeRounds; ++r) {
+        const uint32_t i = r * kBlock + threadIdx.x;
+        if (i < chunk_n) {
+            const int node = (int)__float_as_uint(P.hit[my_slot[r]].y); // -1: nothing, below: a light
+            my_key[r] = node < 0 ? (node == -1 ? 1u : 0u) : ((uint32_t)node + 2u < kShadeBins ? (uint32_t)node + 2u : kShadeBins - 1u);
+            my_rank[r] = atomicAdd(&s_bin[my_key[r]], 1u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) { // bin counts -> bin starts
+        const uint32_t c = threadIdx.x < kShadeBins ? s_bin[threadIdx.x] : 0u;
+        uint32_t inc = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o, 64); if ((int)threadIdx.x >= o) inc += t; }
+        if (threadIdx.x < kShadeBins) s_bin[threadIdx.x] = inc - c;
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t r = 0; r < kShadeRounds; ++r) {
+        const uint32_t i = r * kBlock + threadIdx.x;
+        if (i < chunk_n) s_order[s_bin[my_key[r]] + my_rank[r]] = my_slot[r];
+    }
     __syncthreads();
     for (uint32_t r = 0; r < kShadeRounds; ++r) { // every lane takes every trip: the appends are wave-wide
-        const uint32_t e = chunk * kShadeChunk + r * kBlock + threadIdx.x;
-        const bool live = e < n_in;
+        const uint32_t i = r * kBlock + threadIdx.x;
+        const bool live = i < chunk_n;
         bool want_ext = false, want_shadow = false;
         uint32_t slot = 0;
         float4 new_o = make_float4(0, 0, 0, 0), new_d = new_o, s_o = new_o, s_d = new_o, s_c = new_o;
         if (live) {
-            slot = FIRST ? e : queue_in[e];
+            slot = s_order[i];
             const float4 ro = P.ray_o[slot], rd = P.ray_d[slot];
             const Ray ray{mk(ro.x, ro.y, ro.z), mk(rd.x, rd.y, rd.z)};
             const uint32_t a = slot / (uint32_t)nk;
