@@ -207,8 +207,13 @@ def main():
         sys.exit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+    # RT_BENCH_GROUP=1 takes the N > 1 code path (process group, frame exchange, reductions) with a single rank: a
+    # rehearsal of the multi-GPU path on a one-GPU box
+    grouped = world > 1 or os.environ.get("RT_BENCH_GROUP") == "1"
+    if grouped:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     hs, w, h, (spp_min, spp_max), ntri, mode, bounces, pp = build_scene(args.workload)
     if args.max_bounces is not None:
@@ -224,7 +229,7 @@ def main():
     if args.tile_size:
         prm.tile_size = args.tile_size
     fb = FrameBuffers(w, h, dev)
-    gather = FrameGather(w, h, prm.tile_size, rank, world, dev, ctx=ctx)
+    gather = FrameGather(w, h, prm.tile_size, rank, world, dev, ctx=ctx, exchange=grouped)
     filler = PhotonFill(ctx, rank, world, dev) if pp else None
     host_rgb = torch.empty((w * h, 3), dtype=torch.uint8).pin_memory()
     photon_stats = {}
@@ -242,7 +247,7 @@ def main():
             host_rgb.copy_(fb.rgb, non_blocking=True)
 
     def fence():
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -279,7 +284,7 @@ def main():
     stats = torch.tensor([c.closest_rays, c.shadow_rays, c.camera_paths, counted.box_tests, counted.tri_tests,
                           c.gathers, counted.photon_visits, photon_rays], dtype=torch.float64, device=dev)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if grouped:
         dist.all_reduce(stats)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
@@ -345,7 +350,7 @@ def main():
             if ref:
                 out["cpu_baseline_port"] = port  # our CPU restatement of the same algorithm (the parity oracle), -O3, same cores
         print(json.dumps(out))
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()

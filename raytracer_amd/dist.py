@@ -72,10 +72,12 @@ class FrameGather:
     pixel in the exchange array is arithmetic, no index lists); without one (the CPU tests of the N > 1 path) the same
     record layout is produced with torch indexing."""
 
-    def __init__(self, width, height, tile_size, rank, world, device, ctx=None):
+    def __init__(self, width, height, tile_size, rank, world, device, ctx=None, exchange=None):
         self.world, self.rank, self.ctx, self.tile = world, rank, ctx, tile_size
         self.n = frame_records(width, height, tile_size, world)
-        if world == 1:
+        # a single rank has nothing to exchange; exchange=True makes it go through pack / all_gather / unpack all the same
+        self.exchange = world > 1 if exchange is None else bool(exchange)
+        if not self.exchange:
             return
         self.send = torch.zeros((self.n, 4), dtype=torch.int32, device=device)
         self.recv = torch.zeros((world, self.n, 4), dtype=torch.int32, device=device)
@@ -114,7 +116,7 @@ class FrameGather:
         fb.object_id[self.dest] = blk[:, 3]
 
     def __call__(self, fb):
-        if self.world == 1:
+        if not self.exchange:
             return fb
         self.pack(fb)  # on the library's stream, finished when it returns
         dist.all_gather_into_tensor(self.recv.view(-1), self.send.view(-1))
