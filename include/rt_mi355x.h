@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 4
+#define RT_ABI_VERSION 5
 
 typedef struct rt_ctx rt_ctx;
 
@@ -88,6 +88,12 @@ typedef struct rt_mesh {
     const rt_bvh_node *bvh_nodes; uint32_t n_bvh_nodes; /* including the unused node 0 */
     const uint32_t *bvh_elements;       /* face ids referenced by the leaves [nf] */
     uint32_t bvh_depth;                 /* depth of the deepest leaf, root = 0 */
+    /* Sub-materials of an OBJ file that names materials (`usemtl`): the reference turns them into one MultiMtl
+     * (src/xmlload.cpp:298-322, src/materials.h:350-382) whose members are picked by HitInfo::mtlID.  Here the
+     * members are n_sub_materials consecutive entries of rt_scene_desc.materials starting at the node's material,
+     * and face_material[face] (< n_sub_materials) is the member the face names (cyTriMesh::GetMaterialIndex). */
+    const uint32_t *face_material;      /* [nf], or NULL: the mesh has no sub-materials */
+    uint32_t n_sub_materials;           /* 0 when face_material is NULL */
 } rt_mesh;
 
 /* Blinn material constants (reference: MtlBasePhongBlinn, src/materials.h:52-60). */
@@ -140,6 +146,10 @@ typedef struct rt_scene_desc {
                                     uvw = ray direction (src/main.cpp:175), the Whitted-style shader at the pixel's
                                     (u, v, 1) (project12.zip src/main.cpp:224-226) */
     int32_t environment_texture; /* likewise, evaluated through EvalEnvironment (src/scene.h:390-397) */
+    int32_t face_materials;      /* 0: as the reference renders - no intersector ever sets HitInfo::mtlID (it stays 0,
+                                    src/scene.h:92, src/TriObj.cpp:12-137), so every face of a mesh with sub-materials
+                                    is shaded with the first one.  1: a face is shaded with the sub-material it names
+                                    (node material + rt_mesh.face_material[face]) */
 } rt_scene_desc;
 
 /* Camera as the reference holds it after Camera::Load (src/scene.h:458-480,
@@ -369,6 +379,16 @@ void rt_scene_host_free(rt_scene_host *s);
  * scene and bind it to the node called node_name. */
 int rt_scene_host_set_mesh(rt_scene_host *s, const char *node_name, const float *v, const float *vt,
                            uint32_t nv, const uint32_t *f, uint32_t nf, char *err, size_t err_len);
+
+/* rt_scene_desc.face_materials of a loaded scene: 0 (as loaded) shades every face of an OBJ object that brings its own
+ * materials with the first of them, as the reference does; 1 shades a face with the material its `usemtl` group names. */
+int rt_scene_host_set_face_materials(rt_scene_host *s, int on);
+/* Warnings of the loader (things the reference reports with a printf and goes on): n-th text, or NULL past the last. */
+const char *rt_scene_host_warning(const rt_scene_host *s, uint32_t n);
+
+/* A PNG file in memory -> 8-bit RGB rows, top row first (what the reference asks lodepng for when it loads a texture,
+ * src/texture.cpp:77-87).  *rgb is freed with rt_free. */
+int rt_png_decode_rgb8(const uint8_t *file, size_t size, int32_t *width, int32_t *height, uint8_t **rgb, char *err, size_t err_len);
 
 /* BVH build over nf triangles; returns arrays the caller frees with rt_free. */
 int rt_bvh_build(const float *v, uint32_t nv, const uint32_t *f, uint32_t nf, uint32_t max_leaf,

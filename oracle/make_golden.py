@@ -12,6 +12,8 @@ reference source text.
     python oracle/make_golden.py --photons  # only the photon-map fixtures
     python oracle/make_golden.py --config-c       # only the full-size 1M-triangle band and ray fixture
     python oracle/make_golden.py --photons-large  # only the tall photon map
+    python oracle/make_golden.py --png            # only the PNG decoding cases
+    python oracle/make_golden.py --multimtl       # only the OBJ-with-materials scene
 """
 import os
 import subprocess
@@ -168,8 +170,49 @@ def photons_large():
     save("photons_a_large", **sa, params=np.array([13, 36000, 17000, 64, 2 | 4], np.int64), radius=np.float32(3), **r)
 
 
+def png():
+    """PNG texture files of every colour type and bit depth, plain and interlaced, decoded by the reference's own
+    decoder as its texture loader calls it: the file bytes and the 8-bit RGB pixels it delivers."""
+    cases = scenes.png_cases()
+    with tempfile.TemporaryDirectory() as tmp:
+        names = sorted(cases)
+        for n in names:
+            open(os.path.join(tmp, n + ".png"), "wb").write(cases[n])
+        r = run("-", "png", *[os.path.join(tmp, n + ".png") for n in names])
+        arrays = {}
+        for i, n in enumerate(names):
+            assert r[f"png{i}"].size, f"the reference's decoder refuses {n}"
+            arrays["file_" + n] = np.frombuffer(cases[n], np.uint8)
+            arrays["rgb_" + n] = r[f"png{i}"]
+        save("png_cases", **arrays)
+
+
+def multi_material():
+    """An OBJ object that brings its own materials (usemtl groups, a material library; no material attribute on the
+    node): the scene as the reference loads it - the members of the MultiMtl, the regrouped faces and their
+    sub-material indices - and an image of the snapshot's Whitted-style shader, which shades through MultiMtl::Shade.
+    (The path tracer at HEAD casts the node's material to a Blinn material unchecked, src/main.cpp:212: undefined for
+    a MultiMtl, so there is no path-traced reference image.)"""
+    with tempfile.TemporaryDirectory() as tmp:
+        obj, mtl = scenes.multi_material_mesh()
+        open(os.path.join(tmp, "multi.obj"), "w").write(obj)
+        open(os.path.join(tmp, "multi.mtl"), "w").write(mtl)
+        xml = scenes.multi_material_scene_xml("multi.obj", 96, 54)
+        p = os.path.join(tmp, "scene.xml")
+        open(p, "w").write(xml)
+        H = HARNESS_P12
+        common = dict(xml=np.frombuffer(xml.encode(), np.uint8), obj=np.frombuffer(obj.encode(), np.uint8), mtl=np.frombuffer(mtl.encode(), np.uint8))
+        sc = scene_bundle(p, cwd=tmp, harness=H)
+        out = run(p, "render_whitted", 7, 4, 4, 0.01, 96, 54, 5, cwd=tmp, harness=H)
+        save("whitted_multimtl_96x54_b5", **common, **sc, params=np.array([7, 4, 4, 96, 54, 5], np.int64), delta=np.float32(0.01), **out)
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
+    if "--png" in sys.argv:
+        return png()
+    if "--multimtl" in sys.argv:
+        return multi_material()
     if "--config-c" in sys.argv:
         return config_c()
     if "--photons-large" in sys.argv:
@@ -233,6 +276,8 @@ def main():
     textures()
     config_c()
     photons_large()
+    png()
+    multi_material()
 
 
 if __name__ == "__main__":

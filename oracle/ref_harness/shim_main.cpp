@@ -32,6 +32,7 @@ std::ostream &operator<<(std::ostream &os, std::chrono::duration<R, P> const &d)
 
 #include "objects.h"
 #include "texture.h"
+#include "lodepng.h"
 #include "materials.h" // the snapshot's main.cpp does not pull it in
 
 #include <cstdio>
@@ -121,6 +122,16 @@ static void cmdDumpScene()
     size_t nn = g_preorder.size();
     std::vector<float> tm(nn * 12), itm(nn * 12);
     std::vector<int32_t> parent(nn), prim(nn), mesh(nn), mtl(nn);
+    // the material list with every MultiMtl replaced by its members (a MultiMtl has no constants of its own)
+    std::vector<const Material *> flat;
+    std::vector<int32_t> flat_first, flat_members;
+    for (size_t k = 0; k < sc.materials.size(); ++k) {
+        flat_first.push_back((int32_t)flat.size());
+        if (auto *mm = dynamic_cast<const MultiMtl *>(sc.materials[k])) {
+            for (const Material *m : mm->mtls) flat.push_back(m);
+            flat_members.insert(flat_members.end(), mm->mtls.size(), (int32_t)mm->mtls.size());
+        } else { flat.push_back(sc.materials[k]); flat_members.push_back(0); }
+    }
     for (size_t i = 0; i < nn; ++i) {
         const Node *n = g_preorder[i];
         memcpy(&tm[i * 12], n->GetTransform().cell, 48);
@@ -137,16 +148,17 @@ static void cmdDumpScene()
             }
         }
         mtl[i] = -1;
-        for (size_t k = 0; k < sc.materials.size(); ++k) if (sc.materials[k] == n->GetMaterial()) mtl[i] = (int)k;
+        for (size_t k = 0; k < flat_first.size(); ++k) if (sc.materials[k] == n->GetMaterial()) mtl[i] = flat_first[k];
     }
     dumpF("node_tm", tm, {nn, 12}); dumpF("node_itm", itm, {nn, 12});
     dumpI("node_parent", parent, {nn}); dumpI("node_prim", prim, {nn});
     dumpI("node_mesh", mesh, {nn}); dumpI("node_material", mtl, {nn});
 
-    size_t nm = sc.materials.size();
+    size_t nm = flat.size();
     std::vector<float> m(nm * 20);
+    dumpI("material_members", flat_members, {nm}); // members of the MultiMtl a material belongs to, 0 = an ordinary material
     for (size_t k = 0; k < nm; ++k) {
-        const MtlBasePhongBlinn *b = static_cast<const MtlBasePhongBlinn *>(sc.materials[k]);
+        const MtlBasePhongBlinn *b = static_cast<const MtlBasePhongBlinn *>(flat[k]);
         float *d = &m[k * 20];
         Color c = b->Diffuse().GetValue();    d[0] = c.r; d[1] = c.g; d[2] = c.b;
         c = b->Specular().GetValue();         d[3] = c.r; d[4] = c.g; d[5] = c.b;
@@ -201,7 +213,7 @@ static void cmdDumpScene()
         if (sc.background.GetTexture()) owners.push_back({0, 0, sc.background.GetTexture()});
         if (sc.environment.GetTexture()) owners.push_back({1, 0, sc.environment.GetTexture()});
         for (size_t k = 0; k < nm; ++k) {
-            const MtlBasePhongBlinn *b = static_cast<const MtlBasePhongBlinn *>(sc.materials[k]);
+            const MtlBasePhongBlinn *b = static_cast<const MtlBasePhongBlinn *>(flat[k]);
             if (b->Diffuse().GetTexture()) owners.push_back({2, (int)k, b->Diffuse().GetTexture()});
         }
         const size_t nt = owners.size(), nq = 256;
@@ -212,7 +224,7 @@ static void cmdDumpScene()
             const TextureMap *m = owners[t].map;
             own[t * 2] = owners[t].kind; own[t * 2 + 1] = owners[t].index;
             memcpy(&itm_[t * 12], m->GetInverseTransform().cell, 48);
-            const Texture *tx = m->texture;
+            const Texture *tx = m->texture; // (null for a map whose file could not be read: type 0, evaluates to black)
             if (auto *c = dynamic_cast<const TextureChecker *>(tx)) {
                 type[t] = 1;
                 Color a = c->color[0].GetValue(), b = c->color[1].GetValue();
@@ -259,6 +271,11 @@ static void cmdDumpScene()
         dump(nameOf("f"), "u4", &t->F(0), 4, {t->NF(), 3});
         dump(nameOf("fn"), "u4", &t->FN(0), 4, {t->NF(), 3});
         dump(nameOf("ft"), "u4", &t->FT(0), 4, {t->NF(), 3});
+        if (t->NM() > 0) { // sub-material of every face, as the mesh's own accessor reports it
+            std::vector<int32_t> fm(t->NF());
+            for (unsigned i = 0; i < t->NF(); ++i) fm[i] = t->GetMaterialIndex((int)i);
+            dumpI(nameOf("face_material"), fm, {fm.size()});
+        }
         // walk the BVH through its public accessors to find the node count
         const BVHTriMesh &bvh = t->bvh;
         std::vector<uint32_t> stack{ bvh.GetRootNodeID() };
@@ -906,11 +923,24 @@ int main(int argc, char **argv)
                 "  scene                         dump flattened scene, meshes, BVHs\n"
                 "  render seed min max delta W H [y0 y1]\n"
                 "  kat_rng | kat_trace n seed extent [aimed] | kat_samplers n seed | kat_paths n seed extent\n"
-                "  time threads\n");
+                "  time threads\n"
+                "  png file...                   (first argument ignored) decode PNG files to 8-bit RGB\n");
         return 1;
     }
     g_outdir = argv[2];
     std::string cmd = argv[3];
+    if (cmd == "png") { // decode the files named after the command exactly as TextureFile::LoadFile does (texture.cpp:77-87)
+        for (int i = 4; i < argc; ++i) {
+            std::vector<unsigned char> d;
+            unsigned w = 0, h = 0;
+            const unsigned error = lodepng::decode(d, w, h, argv[i], LCT_RGB);
+            char nm_[32];
+            snprintf(nm_, sizeof nm_, "png%d", i - 4);
+            if (error) { w = h = 0; d.clear(); }
+            dumpB(nm_, d, {h, w, 3});
+        }
+        return 0;
+    }
     if (cmd != "kat_rng") {
         if (!renderer.LoadScene(argv[1])) return 3;
         setupCamera(0, 0);

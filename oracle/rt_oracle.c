@@ -245,12 +245,24 @@ typedef struct {
     v3 uvw;
     int front;
     int light;
+    uint32_t face; /* mesh hits: the triangle */
 } hit_t;
 
 static void hit_init(hit_t *h) /* scene.h:92 */
 {
-    h->z = BIGFLOAT; h->node = -1; h->uvw = V3(0.5f, 0.5f, 0.5f); h->front = 1; h->light = 0;
+    h->z = BIGFLOAT; h->node = -1; h->uvw = V3(0.5f, 0.5f, 0.5f); h->front = 1; h->light = 0; h->face = 0;
     h->p = V3(0, 0, 0); h->n = V3(0, 0, 0);
+}
+
+/* The material of a surface hit.  The reference's intersectors never set HitInfo::mtlID (scene.h:92 leaves it 0), so a
+ * MultiMtl (materials.h:350-382) always answers with its first member: the node's material index here.  A scene may
+ * ask for what the member lookup is meant to do instead (rt_scene_desc.face_materials): the member the face names. */
+static const rt_material *hit_material(const rt_scene_desc *sc, const hit_t *h)
+{
+    const rt_node *nd = &sc->nodes[h->node];
+    int m = nd->material;
+    if (sc->face_materials && nd->prim == RT_PRIM_MESH && sc->meshes[nd->mesh].face_material) m += (int)sc->meshes[nd->mesh].face_material[h->face];
+    return &sc->materials[m];
 }
 
 /* Sphere::IntersectRay, hitSide == HIT_FRONT_AND_BACK (src/Sphere.cpp:7-18,38,57-88) */
@@ -435,6 +447,7 @@ static int mesh_intersect(const rt_mesh *m, ray_t r, hit_t *h, orc_stats *st)
     h->z = closestT;
     h->p = vadd(r.p, vscale(r.d, closestT));
     h->front = cDet > 0.0f;
+    h->face = cFace;
     const uint32_t *nf = &m->fn[cFace * 3];
     const uint32_t *tf = &m->ft[cFace * 3];
     const float w = 1.0f - cU - cV;
@@ -856,7 +869,7 @@ static void trace_path(const rt_scene_desc *sc, ray_t ray, orc_rng *rng, const r
             return;
         }
 
-        const rt_material *mtl = &sc->materials[sc->nodes[h.node].material];
+        const rt_material *mtl = hit_material(sc, &h);
 
         /* next-event estimation (main.cpp:214-251) */
         orc_sample ne;
@@ -1065,7 +1078,7 @@ static int photon_path(const rt_scene_desc *sc, const rt_photon_params *pp, int 
         ray.p = vadd(ray.p, vscale(ray.d, 0.0002f));
         hit_t h; hit_init(&h);
         if (!trace_ray(sc, ray, &h, st) || h.light) return 1;
-        const rt_material *m = &sc->materials[sc->nodes[h.node].material];
+        const rt_material *m = hit_material(sc, &h);
         if (direct_only) {
             if (!is_photon_surface(m)) return 1;
             if (*n >= cap) return 0;
@@ -1355,7 +1368,7 @@ static v3 w_secondary(const wctx *C, const wshade *from, ray_t ray, float *dist)
     if (h.light) return V3(1.0f, 1.0f, 1.0f);
     wshade s;
     s.p = h.p; s.n = vnormalize(h.n); s.v = vneg(vnormalize(ray.d)); s.uvw = h.uvw; s.front = h.front; s.bounce = from->bounce + 1;
-    return whitted_shade(C, &s, &C->sc->materials[C->sc->nodes[h.node].material]);
+    return whitted_shade(C, &s, hit_material(C->sc, &h));
 }
 
 /* (x u + y v) + z n with the reference's association (p12 materials.cpp:96,125,153) */
@@ -1497,7 +1510,7 @@ static v3 whitted_sample(const rt_scene_desc *sc, const rt_render_params *prm, c
     if (h.light) return V3(1.0f, 1.0f, 1.0f);
     wshade s;
     s.p = h.p; s.n = vnormalize(h.n); s.v = vneg(vnormalize(ray.d)); s.uvw = h.uvw; s.front = h.front; s.bounce = 0;
-    return whitted_shade(&C, &s, &sc->materials[sc->nodes[h.node].material]);
+    return whitted_shade(&C, &s, hit_material(sc, &h));
 }
 
 void orc_camera_derive(const rt_camera *cam, float out[12])

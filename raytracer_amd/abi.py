@@ -34,7 +34,8 @@ class Mesh(C.Structure):
     _fields_ = [("v", f32p), ("nv", C.c_uint32), ("vn", f32p), ("nvn", C.c_uint32),
                 ("vt", f32p), ("nvt", C.c_uint32), ("f", u32p), ("fn", u32p), ("ft", u32p),
                 ("nf", C.c_uint32), ("bvh_nodes", C.POINTER(BvhNode)), ("n_bvh_nodes", C.c_uint32),
-                ("bvh_elements", u32p), ("bvh_depth", C.c_uint32)]
+                ("bvh_elements", u32p), ("bvh_depth", C.c_uint32),
+                ("face_material", u32p), ("n_sub_materials", C.c_uint32)]
 
 
 class Material(C.Structure):
@@ -60,7 +61,8 @@ class SceneDesc(C.Structure):
                 ("lights", C.POINTER(Light)), ("n_lights", C.c_uint32),
                 ("background", C.c_float * 3), ("environment", C.c_float * 3),
                 ("textures", C.POINTER(Texture)), ("n_textures", C.c_uint32),
-                ("background_texture", C.c_int32), ("environment_texture", C.c_int32)]
+                ("background_texture", C.c_int32), ("environment_texture", C.c_int32),
+                ("face_materials", C.c_int32)]
 
 
 class Camera(C.Structure):
@@ -197,6 +199,10 @@ def scene_from_arrays(node_tm, node_itm, node_parent, node_prim, node_mesh, node
         ms[i].n_bvh_nodes = b["bvh_nodes"].size // 7
         ms[i].bvh_elements = _ptr(b["bvh_elements"], u32p)
         ms[i].bvh_depth = int(m.get("bvh_depth", 0)) or bvh_depth(b["bvh_nodes"].reshape(-1, 7))
+        if m.get("face_material") is not None:
+            fm = np.ascontiguousarray(m["face_material"], np.uint32)
+            s.keep.append(fm)
+            ms[i].face_material, ms[i].n_sub_materials = _ptr(fm, u32p), int(m["n_sub_materials"])
     s.keep += [nodes, mats, lts, ms]
     d = s.desc
     d.nodes, d.n_nodes = nodes, n

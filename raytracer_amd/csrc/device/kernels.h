@@ -313,7 +313,7 @@ __global__ __launch_bounds__(kBlock) void k_order_keys(DScene S, DFrame F, const
         Hit h;
         Tally<true> tl;
         const bool hit = trace_closest<true, LEVELS>(S, ray, st, h, tl);
-        const rt_material &m = S.materials[hit && h.node >= 0 ? S.nodes[h.node].material : 0];
+        const rt_material &m = S.materials[hit && h.node >= 0 ? hit_material(S, h.node, h.face) : 0];
         // a surface that keeps a path going (glossy, glass) weighs more than one that mostly ends it
         const float keep = hit && h.node >= 0 ? gray(m.specular) + gray(m.refraction) : 0.0f;
         const uint32_t walk = tl.box + 4u * tl.tri;

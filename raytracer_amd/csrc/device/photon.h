@@ -195,7 +195,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_photon_paths(DScene S, rt_photon_
             const bool hit = trace_closest<false, LEVELS>(S, ray, st, h, tl);
             if (hit && h.node >= 0) { // a miss or a light ends the path
                 finish_hit(S, ray, h, false);
-                const rt_material &m = S.materials[S.nodes[h.node].material];
+                const rt_material &m = S.materials[hit_material(S, h.node, h.face)];
                 bool store = false;
                 V3 newDir = mk(0, 0, 0), mult = mk(0, 0, 0);
                 float prob = 1.0f;

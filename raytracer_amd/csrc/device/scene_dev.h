@@ -57,6 +57,7 @@ struct DMesh {
     const float *vt;
     uint32_t n_nodes;
     uint32_t depth;
+    const uint32_t *fmtl; // sub-material per face (rt_mesh::face_material), null unless the scene asks for per-face materials
 };
 
 // One texture map (rt_texture with its pixels in device memory).
@@ -82,6 +83,7 @@ struct DScene {
     const rt_light *lights;
     int32_t n_nodes;
     int32_t n_lights;
+    int32_t face_materials; // some mesh carries fmtl
     float background[3];
     float environment[3]; // what a secondary ray of the Whitted-style shader sees when it leaves the scene
     int32_t stack_levels; // BVH stack entries a lane may need (deepest mesh + 2), 0 without meshes

@@ -278,7 +278,7 @@ RT_DEV bool path_step(const DScene &S, const DFrame &F, PathState &ps, LaneStack
     Surface s; // SamplerInfo::SetHit (renderer.h:145-153)
     const V3 normal = normalize(h.n);
     s.p = h.p; s.n = normal; s.v = -normalize(ray.d); s.front = h.front;
-    const rt_material &mtl = S.materials[S.nodes[h.node].material];
+    const rt_material &mtl = S.materials[hit_material(S, h.node, h.face)];
 
     // next-event estimation (main.cpp:214-251)
     Sample ne;

@@ -508,6 +508,19 @@ RT_DEV void finish_hit(const DScene &S, Ray ray, Hit &h, bool want_uvw)
     }
 }
 
+// The material a surface hit is shaded with: the node's, or - for a mesh whose OBJ file names sub-materials, in a
+// scene that asks for them - the member of the node's MultiMtl the face names (src/materials.h:350-382).
+RT_DEV int hit_material(const DScene &S, int node, uint32_t face)
+{
+    const DNode &nd = S.nodes[node];
+    int m = nd.material;
+    if (S.face_materials && nd.prim == RT_PRIM_MESH) {
+        const GU32 fm = (GU32)S.meshes[nd.mesh].fmtl;
+        if (fm) m += (int)fm[face];
+    }
+    return m;
+}
+
 // shootShadowRay (src/main.cpp:72-89,122-125): any hit with t < t_max.
 // Without CULL a lane leaves at its first occluder.  With CULL the lanes vote per node, so they stay in the node loop
 // together: a lane that has found its occluder idles until every lane has one or the list ends (the vote is then

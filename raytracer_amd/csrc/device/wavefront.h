@@ -290,7 +290,7 @@ __global__ __launch_bounds__(kBlock) void k_wf_shade(DScene S, DFrame F, const i
                 Surface s; // SamplerInfo::SetHit (renderer.h:145-153)
                 const V3 normal = normalize(h.n);
                 s.p = h.p; s.n = normal; s.v = -normalize(ray.d); s.front = h.front;
-                const rt_material &mtl = S.materials[S.nodes[h.node].material];
+                const rt_material &mtl = S.materials[hit_material(S, h.node, h.face)];
                 // next-event estimation (main.cpp:214-251): the shadow ray is always sent, as in the reference; what it
                 // gates is worked out now, with this vertex' throughput
                 Sample ne;

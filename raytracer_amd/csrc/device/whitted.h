@@ -206,7 +206,7 @@ __global__ __launch_bounds__(kBlock, RT_WHITTED_MIN_WAVES) void k_whitted(DScene
                 retDist = h.z;
                 state = W_RET;
             } else {
-                mtl = S.nodes[h.node].material;
+                mtl = hit_material(S, h.node, h.face);
                 const rt_material &hm = S.materials[mtl];
                 finish_hit(S, ray, h, hm.diffuse_texture > 0);
                 cur.kd = textured_color(S, hm.diffuse, hm.diffuse_texture, h.uvw);

@@ -1,4 +1,5 @@
 // extern "C" entry points that need no GPU: scene.xml / OBJ reading and the BVH build.
+#include "png_reader.h"
 #include "scene_host.h"
 
 #include <cstdio>
@@ -74,6 +75,7 @@ int rt_scene_host_set_mesh(rt_scene_host *s, const char *node_name, const float 
         m.vt.assign(vt, vt + (size_t)nv * 3);
         m.f.assign(f, f + (size_t)nf * 3);
         m.ft = m.f;
+        m.mtls.clear(); m.face_mtl.clear(); // an in-memory mesh brings no materials
         rt::compute_normals(m);
         rt::build_bvh(m.v.data(), m.f.data(), nf, 4, m.bvh, m.elements, m.depth);
     } catch (const std::exception &ex) {
@@ -81,6 +83,34 @@ int rt_scene_host_set_mesh(rt_scene_host *s, const char *node_name, const float 
         return RT_ERR_INVALID;
     }
     s->refresh_desc();
+    return RT_OK;
+}
+
+int rt_scene_host_set_face_materials(rt_scene_host *s, int on)
+{
+    if (!s) return RT_ERR_INVALID;
+    s->desc.face_materials = on ? 1 : 0;
+    return RT_OK;
+}
+
+const char *rt_scene_host_warning(const rt_scene_host *s, uint32_t n) { return s && n < s->warnings.size() ? s->warnings[n].c_str() : nullptr; }
+
+int rt_png_decode_rgb8(const uint8_t *file, size_t size, int32_t *width, int32_t *height, uint8_t **rgb, char *err, size_t err_len)
+{
+    if (!file || !width || !height || !rgb) { set_err(err, err_len, "null argument"); return RT_ERR_INVALID; }
+    std::vector<uint8_t> px;
+    std::string why;
+    int w = 0, h = 0;
+    try {
+        if (!rt::decode_png_rgb8(file, size, w, h, px, why)) { set_err(err, err_len, why); return RT_ERR_IO; }
+    } catch (const std::exception &ex) {
+        set_err(err, err_len, ex.what());
+        return RT_ERR_IO;
+    }
+    *rgb = (uint8_t *)malloc(px.size() ? px.size() : 1);
+    if (!*rgb) { set_err(err, err_len, "out of memory"); return RT_ERR_IO; }
+    memcpy(*rgb, px.data(), px.size());
+    *width = w; *height = h;
     return RT_OK;
 }
 

@@ -21,6 +21,7 @@ rt_mesh HostMesh::desc() const
     d.f = f.data(); d.fn = fn.data(); d.ft = ft.data(); d.nf = nf();
     d.bvh_nodes = bvh.data(); d.n_bvh_nodes = (uint32_t)bvh.size();
     d.bvh_elements = elements.data(); d.bvh_depth = depth;
+    if (!mtls.empty() && face_mtl.size() == nf()) { d.face_material = face_mtl.data(); d.n_sub_materials = (uint32_t)mtls.size(); }
     return d;
 }
 
@@ -66,6 +67,50 @@ void read3(const std::string &l, size_t off, std::vector<float> &dst)
     dst.push_back(x); dst.push_back(y); dst.push_back(z);
 }
 
+// three floats after a two-letter keyword; a single value stands for all three (cyTriMesh.h:306)
+void read_rgb(const std::string &l, float c[3])
+{
+    c[0] = c[1] = c[2] = 0;
+    if (l.size() <= 2) return;
+    const int n = sscanf(l.c_str() + 2, "%f %f %f", &c[0], &c[1], &c[2]);
+    if (n == 1) c[2] = c[1] = c[0];
+}
+
+std::string after(const std::string &l, size_t start)
+{
+    while (start < l.size() && l[start] <= ' ') ++start;
+    return start < l.size() ? l.substr(start) : "";
+}
+
+// A material library (cyTriMesh.h:511-543): only materials some face names are kept; a library that cannot be
+// opened leaves them at their defaults, as in the reference.
+void load_mtl(const std::string &path, std::vector<ObjMaterial> &mtls)
+{
+    FILE *fp = fopen(path.c_str(), "r");
+    if (!fp) return;
+    std::string line;
+    int cur = -1;
+    while (next_line(fp, line)) {
+        if (is_cmd(line, "newmtl")) {
+            cur = -1;
+            const std::string name = line.size() > 7 ? line.substr(7) : "";
+            for (size_t i = 0; i < mtls.size(); ++i) if (mtls[i].name == name) { cur = (int)i; break; }
+        } else if (cur >= 0) {
+            ObjMaterial &m = mtls[(size_t)cur];
+            if (is_cmd(line, "Ka")) read_rgb(line, m.Ka);
+            else if (is_cmd(line, "Kd")) read_rgb(line, m.Kd);
+            else if (is_cmd(line, "Ks")) read_rgb(line, m.Ks);
+            else if (is_cmd(line, "Tf")) read_rgb(line, m.Tf);
+            else if (is_cmd(line, "Ns")) { if (line.size() > 2) sscanf(line.c_str() + 2, "%f", &m.Ns); }
+            else if (is_cmd(line, "Ni")) { if (line.size() > 2) sscanf(line.c_str() + 2, "%f", &m.Ni); }
+            else if (is_cmd(line, "illum")) { if (line.size() > 5) sscanf(line.c_str() + 5, "%d", &m.illum); }
+            else if (is_cmd(line, "map_Kd")) m.map_Kd = after(line, 7);
+            else if (is_cmd(line, "map_Ks")) m.map_Ks = after(line, 7);
+        }
+    }
+    fclose(fp);
+}
+
 } // namespace
 
 bool load_obj(const std::string &path, HostMesh &m, std::string &err)
@@ -75,7 +120,7 @@ bool load_obj(const std::string &path, HostMesh &m, std::string &err)
     std::vector<float> v, vt, vn;
     std::vector<uint32_t> f, ft, fn;
     std::vector<int> face_mtl;
-    std::vector<std::string> mtl_names;
+    std::vector<std::string> mtl_names, mtl_libs;
     int cur_mtl = -1;
     std::string line;
     while (next_line(fp, line)) {
@@ -125,7 +170,7 @@ bool load_obj(const std::string &path, HostMesh &m, std::string &err)
                 for (size_t i = 0; i < mtl_names.size(); ++i) if (mtl_names[i] == name) cur_mtl = (int)i;
                 if (cur_mtl < 0) { mtl_names.push_back(name); cur_mtl = (int)mtl_names.size() - 1; }
             }
-        }
+        } else if (is_cmd(line, "mtllib") && line.size() > 7) mtl_libs.push_back(line.substr(7));
     }
     fclose(fp);
     if (f.empty()) { err = "OBJ file " + path + " has no faces"; return false; }
@@ -144,6 +189,14 @@ bool load_obj(const std::string &path, HostMesh &m, std::string &err)
             a.swap(o);
         };
         permute(f); permute(ft); permute(fn);
+        // a face's sub-material (cyTriMesh::GetMaterialIndex); faces outside every group count as the first
+        m.face_mtl.resize(order.size());
+        for (size_t k = 0; k < order.size(); ++k) m.face_mtl[k] = face_mtl[order[k]] < 0 ? 0u : (uint32_t)face_mtl[order[k]];
+        const size_t slash = path.find_last_of("/\\");
+        m.dir = slash == std::string::npos ? "" : path.substr(0, slash + 1);
+        m.mtls.resize(mtl_names.size());
+        for (size_t i = 0; i < mtl_names.size(); ++i) m.mtls[i].name = mtl_names[i];
+        for (const std::string &lib : mtl_libs) load_mtl(m.dir + lib, m.mtls);
     }
     m.v.swap(v); m.f.swap(f);
     if (vt.empty()) { vt.assign(3, 0.0f); ft.assign(m.f.size(), 0u); }

@@ -9,6 +9,15 @@
 
 namespace rt {
 
+// One material of an OBJ file's material library, with the defaults of cyTriMesh::Mtl (cyTriMesh.h:75-104)
+struct ObjMaterial {
+    std::string name;
+    float Ka[3] = {0, 0, 0}, Kd[3] = {1, 1, 1}, Ks[3] = {0, 0, 0}, Tf[3] = {0, 0, 0};
+    float Ns = 0, Ni = 1;
+    int illum = 2;
+    std::string map_Kd, map_Ks;
+};
+
 struct HostMesh {
     std::string name;
     std::vector<float> v, vn, vt;       // 3 floats per entry
@@ -16,13 +25,18 @@ struct HostMesh {
     std::vector<rt_bvh_node> bvh;       // node 0 unused, node 1 = root
     std::vector<uint32_t> elements;
     uint32_t depth = 0;
+    std::vector<ObjMaterial> mtls;      // the materials the file's faces name (`usemtl`), in order of first use
+    std::vector<uint32_t> face_mtl;     // per face: index into mtls (empty when the file names none)
+    bool members_created = false;       // the scene loader has turned mtls into materials of the scene
+    std::string dir;                    // directory of the OBJ file ("" = working directory), with its trailing separator
 
     uint32_t nf() const { return (uint32_t)(f.size() / 3); }
     rt_mesh desc() const;
 };
 
 // OBJ text -> mesh arrays, fan-triangulated, faces grouped by `usemtl` in order
-// of first use (cyTriMesh.h:264-497).  Normals are computed when the file has none.
+// of first use (cyTriMesh.h:264-497), the named materials read from the file's `mtllib`
+// libraries (cyTriMesh.h:499-545).  Normals are computed when the file has none.
 bool load_obj(const std::string &path, HostMesh &m, std::string &err);
 // Area-weighted vertex normals, one per position, fn = f (cyTriMesh.h:249-262).
 void compute_normals(HostMesh &m);

@@ -2,6 +2,7 @@
 // (src/xmlload.cpp:41-270, src/xmlload.h:58-63) so that a scene file means the
 // same thing on both sides of the C ABI: same defaults, same attribute
 // handling, same order of transform composition, nodes in depth-first order.
+#include "png_reader.h"
 #include "scene_host.h"
 #include "xform.h"
 #include "xml_reader.h"
@@ -83,6 +84,7 @@ struct Loader {
     std::string base_dir;
     std::string err;
     std::vector<std::string> node_material_names; // per node, "" = none
+    std::vector<int> node_sub_materials;          // per node: 1 = an OBJ node without a material attribute whose file names materials
 
     bool file_exists(const std::string &p) { struct stat st; return stat(p.c_str(), &st) == 0; }
 
@@ -126,6 +128,26 @@ struct Loader {
         return ok;
     }
 
+    // ReadTextureFile + TextureFile::LoadFile (xmlload.cpp:356-371, texture.cpp:62-96): the last three letters of the
+    // name, whatever their case, say PNG or PPM; anything else, or a file that cannot be decoded, is no texture
+    bool read_texture_file(const char *name, rt_texture &t, std::vector<uint8_t> &px)
+    {
+        const size_t len = strlen(name);
+        std::string path = name;
+        if (!file_exists(path) && !base_dir.empty()) path = base_dir + "/" + name;
+        bool ok = false;
+        std::string why;
+        if (len >= 3 && ieq(name + len - 3, "ppm")) ok = load_ppm(path, t.width, t.height, px);
+        else if (len >= 3 && ieq(name + len - 3, "png")) ok = load_png_rgb8(path, t.width, t.height, px, why);
+        else why = "neither a PNG nor a PPM name";
+        if (!ok) {
+            S.warnings.push_back(std::string("cannot read texture file ") + name + (why.empty() ? "" : ": " + why));
+            return false;
+        }
+        t.type = RT_TEX_IMAGE;
+        return true;
+    }
+
     // Loader::ReadTextureMap (xmlload.cpp:326-344): "checkerboard" with <color1>/<color2>, or an image file; the element's
     // scale / rotate / translate children are the texture transformation.  Returns 1 + texture index, 0 = no texture.
     int read_texture_map(const XmlElement *e)
@@ -142,19 +164,7 @@ struct Loader {
             read_color(e->child("color2"), t.color2);
             if ((e->child("color1") && e->child("color1")->attr("texture")) || (e->child("color2") && e->child("color2")->attr("texture")))
                 S.warnings.push_back("textures inside a checkerboard's colours are not supported: their values are used");
-        } else {
-            const size_t len = strlen(name);
-            std::string path = name;
-            if (!file_exists(path) && !base_dir.empty()) path = base_dir + "/" + name;
-            bool ok = false;
-            if (len >= 3 && ieq(name + len - 3, "ppm")) ok = load_ppm(path, t.width, t.height, px);
-            else S.warnings.push_back(std::string("texture ") + name + ": only PPM image files are read here (convert PNG files)");
-            if (!ok) { // the reference prints an error and goes on without the texture (xmlload.cpp:356-371)
-                S.warnings.push_back(std::string("cannot read texture file ") + name);
-                return 0;
-            }
-            t.type = RT_TEX_IMAGE;
-        }
+        } else if (!read_texture_file(name, t, px)) return 0; // the reference prints an error and goes on without the texture (xmlload.cpp:337-339,356-371)
         Mat34 tm = Mat34::identity(), itm = Mat34::identity();
         load_transform(*e, tm, itm);
         memcpy(t.itm, itm.c, sizeof t.itm);
@@ -231,6 +241,9 @@ struct Loader {
         S.nodes.push_back(n);
         S.node_names.push_back(name ? name : "");
         node_material_names.push_back(mtl ? mtl : "");
+        // xmlload.cpp:157: such a node gets the materials of its OBJ file (decided when the file is loaded: a mesh filled in
+        // later through rt_scene_host_set_mesh has none)
+        node_sub_materials.push_back(!mtl && n.prim == RT_PRIM_MESH && !S.meshes[(size_t)n.mesh]->mtls.empty() ? 1 : 0);
         for (auto &c : e.children)
             if (ieq(c->tag.c_str(), "object") && !load_node(*c, me)) return false;
         return true;
@@ -288,6 +301,53 @@ struct Loader {
         S.material_names.push_back(name ? name : "");
     }
 
+    // SetNodeMaterials + CreateMultiMtl (xmlload.cpp:278-286,298-322): the materials of an OBJ file become one MultiMtl
+    // named after the node, looked up by that name first (a material of the scene file, or an earlier node's, with the
+    // same name wins).  Here the MultiMtl is its members as consecutive materials; the first carries the name.
+    // Returns the index of the first member.
+    int multi_material(const std::string &node_name, HostMesh &mesh)
+    {
+        for (size_t k = 0; k < S.material_names.size(); ++k)
+            if (S.material_names[k] == node_name) {
+                if (!mesh.members_created) { // an ordinary material of that name: it has no members for the faces to pick from
+                    S.warnings.push_back("material " + node_name + " stands in for the materials of the OBJ file of the same name");
+                    mesh.face_mtl.clear();
+                }
+                return (int)k;
+            }
+        mesh.members_created = true;
+        const int first = (int)S.materials.size();
+        for (size_t i = 0; i < mesh.mtls.size(); ++i) {
+            const ObjMaterial &o = mesh.mtls[i];
+            rt_material m{};
+            for (int c = 0; c < 3; ++c) { m.diffuse[c] = o.Kd[c]; m.specular[c] = o.Ks[c]; }
+            m.glossiness = o.Ns;
+            m.ior = o.Ni;
+            // (the second line of the reference sets the DIFFUSE texture again, from map_Ks: xmlload.cpp:310)
+            const std::string &map = !o.map_Ks.empty() ? o.map_Ks : o.map_Kd;
+            if (!map.empty()) m.diffuse_texture = obj_texture(map);
+            if (o.illum > 2 && o.illum <= 7) {
+                for (int c = 0; c < 3; ++c) m.reflection[c] = o.Ks[c];
+                if (o.illum >= 6) for (int c = 0; c < 3; ++c) m.refraction[c] = 1 - o.Tf[c];
+            }
+            S.materials.push_back(m);
+            S.material_names.push_back(i == 0 ? node_name : node_name + "#" + std::to_string(i));
+        }
+        return first;
+    }
+    // new TextureMap(ReadTextureFile(...)) (xmlload.cpp:309-310): identity transformation; a file that cannot be read
+    // leaves a map without a texture, which evaluates to black (scene.h:350) - here an image of no pixels
+    int obj_texture(const std::string &name)
+    {
+        rt_texture t{};
+        std::vector<uint8_t> px;
+        if (!read_texture_file(name.c_str(), t, px)) { t.type = RT_TEX_IMAGE; t.width = t.height = 0; px.clear(); }
+        memcpy(t.itm, Mat34::identity().c, sizeof t.itm);
+        S.textures.push_back(t);
+        S.texture_pixels.push_back(std::move(px));
+        return (int)S.textures.size();
+    }
+
     // Camera::Load (xmlload.cpp:104-120), defaults from scene.h:466-477
     void load_camera(const XmlElement &e)
     {
@@ -331,6 +391,7 @@ struct Loader {
         S.nodes.push_back(root);
         S.node_names.push_back("");
         node_material_names.push_back("");
+        node_sub_materials.push_back(0);
 
         // Scene::Load (xmlload.cpp:80-100). The reference appends every top-level
         // object to the root in file order; nested objects follow their parent, so a
@@ -346,6 +407,7 @@ struct Loader {
         }
         // SetNodeMaterials (xmlload.cpp:274-294): names resolved after all materials are known, exact match
         for (size_t i = 0; i < S.nodes.size(); ++i) {
+            if (node_sub_materials[i]) { S.nodes[i].material = multi_material(S.node_names[i], *S.meshes[(size_t)S.nodes[i].mesh]); continue; }
             const std::string &mn = node_material_names[i];
             if (mn.empty()) continue;
             for (size_t k = 0; k < S.material_names.size(); ++k)
@@ -361,7 +423,7 @@ struct Loader {
 
 bool load_scene_xml(const std::string &xml, const std::string &base_dir, rt_scene_host &out, std::string &err)
 {
-    Loader L{out, base_dir, {}, {}};
+    Loader L{out, base_dir, {}, {}, {}};
     // TexturedColor default-constructs to black (scene.h:376)
     for (int i = 0; i < 3; ++i) out.desc.background[i] = out.desc.environment[i] = 0.0f;
     if (!L.load(xml)) { err = L.err; return false; }

@@ -522,6 +522,11 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc)
         }
         if (n.prim == RT_PRIM_MESH) {
             if (n.mesh < 0 || n.mesh >= (int)sc->n_meshes) return ctx->fail(RT_ERR_INVALID, "node %u: mesh index out of range", i);
+            // a mesh with sub-materials: the node's material is the first of that many consecutive ones
+            const rt_mesh &m = sc->meshes[n.mesh];
+            if (sc->face_materials && m.face_material && (uint64_t)n.material + m.n_sub_materials > sc->n_materials)
+                return ctx->fail(RT_ERR_INVALID, "node %u: the mesh names %u sub-materials but only %u materials follow the node's", i,
+                                 m.n_sub_materials, sc->n_materials - (uint32_t)n.material);
         }
     }
     if (sc->n_lights < 1 || !sc->lights || sc->lights[0].type != RT_LIGHT_POINT || !(sc->lights[0].size > 0.0f))
@@ -529,6 +534,7 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc)
 
     // ---- meshes: BVH nodes and triangle records of all meshes go into two pools; ids in the data words become pool ids ----
     std::vector<DMesh> dmeshes(sc->n_meshes);
+    bool any_face_materials = false;
     std::vector<std::unique_ptr<DeviceBuf>> bufs;
     auto upload = [&](const void *src, size_t bytes, const void **dst) -> hipError_t {
         auto b = std::make_unique<DeviceBuf>();
@@ -649,6 +655,13 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc)
         HIP_TRY(ctx, upload(m.ft, (size_t)m.nf * 12, (const void **)&d.ft));
         HIP_TRY(ctx, upload(m.vn, (size_t)m.nvn * 12, (const void **)&d.vn));
         HIP_TRY(ctx, upload(m.vt, (size_t)m.nvt * 12, (const void **)&d.vt));
+        d.fmtl = nullptr;
+        if (sc->face_materials && m.face_material) {
+            for (uint32_t k = 0; k < m.nf; ++k)
+                if (m.face_material[k] >= m.n_sub_materials) return ctx->fail(RT_ERR_INVALID, "mesh %u: face %u names sub-material %u of %u", mi, k, m.face_material[k], m.n_sub_materials);
+            HIP_TRY(ctx, upload(m.face_material, (size_t)m.nf * 4, (const void **)&d.fmtl));
+            any_face_materials = true;
+        }
     }
     const float4 *d_bvh_pool = nullptr, *d_tri_pool = nullptr, *d_bvh4_pool = nullptr;
     if (sc->n_meshes) {
@@ -767,6 +780,7 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc)
     S.materials = ctx->d_materials.as<rt_material>();
     S.lights = ctx->d_lights.as<rt_light>();
     S.n_nodes = (int)nn; S.n_lights = (int)sc->n_lights;
+    S.face_materials = any_face_materials ? 1 : 0;
     memcpy(S.background, sc->background, 12);
     memcpy(S.environment, sc->environment, 12);
     ctx->mesh_bufs.swap(bufs);

@@ -20,7 +20,8 @@ SYMBOLS = (
     "rt_abi_version", "rt_init", "rt_shutdown", "rt_last_error", "rt_scene_upload", "rt_camera_set", "rt_render",
     "rt_trace", "rt_trace_shadow", "rt_trace_brief", "rt_trace_brief_noalloc", "rt_trace_paths", "rt_get_counters", "rt_set_counting",
     "rt_scene_load_xml", "rt_scene_from_xml_string", "rt_scene_host_desc", "rt_scene_host_camera",
-    "rt_scene_host_free", "rt_scene_host_set_mesh", "rt_bvh_build", "rt_free",
+    "rt_scene_host_free", "rt_scene_host_set_mesh", "rt_scene_host_set_face_materials", "rt_scene_host_warning", "rt_png_decode_rgb8",
+    "rt_bvh_build", "rt_free",
     "rt_cancel", "rt_progress", "rt_frame_records", "rt_frame_pack", "rt_frame_unpack", "rt_photons_emit", "rt_photons_build", "rt_photons_fill", "rt_photons_download", "rt_photons_irradiance",
 )
 
@@ -79,6 +80,10 @@ def load():
     L.rt_scene_host_free.restype = None
     L.rt_scene_host_set_mesh.argtypes = [vp, C.c_char_p, abi.f32p, abi.f32p, C.c_uint32, abi.u32p, C.c_uint32,
                                          C.c_char_p, C.c_size_t]
+    L.rt_scene_host_set_face_materials.argtypes = [vp, C.c_int]
+    L.rt_scene_host_warning.argtypes = [vp, C.c_uint32]
+    L.rt_scene_host_warning.restype = C.c_char_p
+    L.rt_png_decode_rgb8.argtypes = [C.c_char_p, C.c_size_t, abi.i32p, abi.i32p, C.POINTER(abi.u8p), C.c_char_p, C.c_size_t]
     L.rt_bvh_build.argtypes = [abi.f32p, C.c_uint32, abi.u32p, C.c_uint32, C.c_uint32,
                                C.POINTER(C.POINTER(abi.BvhNode)), C.POINTER(C.c_uint32),
                                C.POINTER(abi.u32p), C.POINTER(C.c_uint32)]
@@ -130,6 +135,18 @@ class HostScene:
             raise RtError(rc, err.value.decode())
         self.desc = load().rt_scene_host_desc(self._h).contents
 
+    def set_face_materials(self, on):
+        """Shade the faces of an OBJ object that brings its own materials each with the one it names (the reference
+        shades them all with the first: it never sets HitInfo::mtlID)."""
+        load().rt_scene_host_set_face_materials(self._h, int(on))
+
+    def warnings(self):
+        out, n = [], 0
+        while (w := load().rt_scene_host_warning(self._h, n)) is not None:
+            out.append(w.decode())
+            n += 1
+        return out
+
     def close(self):
         if self._h:
             load().rt_scene_host_free(self._h)
@@ -137,6 +154,18 @@ class HostScene:
 
     def __del__(self):
         self.close()
+
+
+def png_decode(data):
+    """PNG file bytes -> uint8 array [height, width, 3] (rt_png_decode_rgb8)."""
+    w, h, px, err = C.c_int32(), C.c_int32(), abi.u8p(), C.create_string_buffer(256)
+    rc = load().rt_png_decode_rgb8(data, len(data), C.byref(w), C.byref(h), C.byref(px), err, len(err))
+    if rc:
+        raise RtError(rc, err.value.decode())
+    try:
+        return np.ctypeslib.as_array(px, shape=(h.value, w.value, 3)).copy()
+    finally:
+        load().rt_free(px)
 
 
 def bvh_build(v, f, max_leaf=4):

@@ -355,3 +355,163 @@ def textured_scene_xml(image="tex.ppm", width=96, height=54):
   </camera>
 </xml>
 """
+
+
+# ---- PNG files (texture assets for the tests: every colour type, bit depth, filter type, interlaced or not) ----
+def _png_pack_rows(samples, depth):
+    """[h, w, channels] integer samples -> list of packed scanlines (bytes)."""
+    h, w, ch = samples.shape
+    if depth == 8:
+        return [samples[y].astype(np.uint8).tobytes() for y in range(h)]
+    if depth == 16:
+        return [samples[y].astype(">u2").tobytes() for y in range(h)]
+    per = 8 // depth
+    rows = []
+    for y in range(h):
+        flat = samples[y].reshape(-1).astype(np.uint8)
+        flat = np.concatenate([flat, np.zeros((-len(flat)) % per, np.uint8)]).reshape(-1, per)
+        b = np.zeros(len(flat), np.uint8)
+        for k in range(per):
+            b |= flat[:, k] << (8 - depth * (k + 1))
+        rows.append(b.tobytes())
+    return rows
+
+
+def _png_filter(rows, bpp):
+    """Scanlines -> filtered stream; row y uses filter type y % 5 (all five types appear)."""
+    out, prev = bytearray(), None
+    for y, row in enumerate(rows):
+        t = y % 5
+        cur = np.frombuffer(row, np.uint8).astype(np.int32)
+        up = np.frombuffer(prev, np.uint8).astype(np.int32) if prev is not None else np.zeros_like(cur)
+        left = np.concatenate([np.zeros(bpp, np.int32), cur[:-bpp]]) if len(cur) > bpp else np.zeros_like(cur)
+        upleft = np.concatenate([np.zeros(bpp, np.int32), up[:-bpp]]) if len(cur) > bpp else np.zeros_like(cur)
+        if t == 0:
+            f = cur
+        elif t == 1:
+            f = cur - left
+        elif t == 2:
+            f = cur - up
+        elif t == 3:
+            f = cur - (left + up) // 2
+        else:
+            p = left + up - upleft
+            pa, pb, pc = abs(p - left), abs(p - up), abs(p - upleft)
+            pred = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, up, upleft))
+            f = cur - pred
+        out.append(t)
+        out += (f & 255).astype(np.uint8).tobytes()
+        prev = row
+    return bytes(out)
+
+
+def png_bytes(samples, color_type, depth, interlace=False, palette=None):
+    """A PNG file of the given colour type (0 grey, 2 RGB, 3 palette, 4 grey+alpha, 6 RGBA) and bit depth from integer
+    samples [h, w, channels]; rows cycle through the five filter types; interlace=True writes the seven Adam7 passes."""
+    import struct
+    import zlib
+    samples = np.asarray(samples)
+    h, w, ch = samples.shape
+    bits = ch * depth
+    bpp = max(1, bits // 8)
+
+    def chunk(tag, body):
+        return struct.pack(">I", len(body)) + tag + body + struct.pack(">I", zlib.crc32(tag + body) & 0xFFFFFFFF)
+
+    stream = b""
+    if interlace:
+        for sx, sy, dx, dy in ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)):
+            sub = samples[sy::dy, sx::dx]
+            if sub.shape[0] and sub.shape[1]:
+                stream += _png_filter(_png_pack_rows(sub, depth), bpp)
+    else:
+        stream = _png_filter(_png_pack_rows(samples, depth), bpp)
+    out = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, color_type, 0, 0, 1 if interlace else 0))
+    if palette is not None:
+        out += chunk(b"PLTE", np.asarray(palette, np.uint8).tobytes())
+    out += chunk(b"tEXt", b"Comment\x00generated test asset")
+    comp = zlib.compress(stream, 9)
+    half = len(comp) // 2
+    out += chunk(b"IDAT", comp[:half]) + chunk(b"IDAT", comp[half:])  # image data may be split over chunks
+    return out + chunk(b"IEND", b"")
+
+
+def png_cases(seed=11, width=13, height=11):
+    """{name: PNG file bytes}: every legal (colour type, bit depth) pair, plain and interlaced."""
+    rng = np.random.RandomState(seed)
+    cases = {}
+    for ctype, depths, ch in ((0, (1, 2, 4, 8, 16), 1), (2, (8, 16), 3), (3, (1, 2, 4, 8), 1), (4, (8, 16), 2), (6, (8, 16), 4)):
+        for depth in depths:
+            for il in (False, True):
+                pal = None
+                hi = 1 << depth
+                if ctype == 3:
+                    n = min(hi, 200)  # some indices of the 8-bit case point past the palette
+                    pal = rng.randint(0, 256, (n, 3))
+                s = rng.randint(0, hi, (height, width, ch))
+                cases[f"c{ctype}_d{depth}_{'adam7' if il else 'plain'}"] = png_bytes(s, ctype, depth, il, pal)
+    cases["rgb8_1x1"] = png_bytes(rng.randint(0, 256, (1, 1, 3)), 2, 8)
+    cases["rgb8_3x2_adam7"] = png_bytes(rng.randint(0, 256, (2, 3, 3)), 2, 8, True)
+    return cases
+
+
+# ---- an OBJ object that brings its own materials (usemtl groups + a material library) ----
+def multi_material_mesh(nx=12, ny=8):
+    """A small height field whose quads name one of three materials in turn - groups interleaved in the file, so the
+    loader has to regroup the faces.  Returns (obj text, mtl text)."""
+    m = heightfield(nx, ny, 8.0, 5.0)
+    v, vt, f = m["v"], m["vt"], m["f"]
+    lines = ["mtllib multi.mtl"]
+    lines += ["v %.6f %.6f %.6f" % tuple(p) for p in v.astype(np.float64)]
+    lines += ["vt %.6f %.6f %.6f" % tuple(p) for p in vt.astype(np.float64)]
+    names = ("red_matte", "green_gloss", "mirror_blue")
+    for q in range(nx * ny):
+        lines.append("usemtl " + names[(q + q // nx) % 3])
+        for t in (2 * q, 2 * q + 1):
+            a, b, c = (int(i) + 1 for i in f[t])
+            lines.append(f"f {a}/{a} {b}/{b} {c}/{c}")
+    mtl = """# three materials; a fourth that no face names
+newmtl red_matte
+Kd 0.8 0.15 0.1
+Ks 0.05
+Ns 12
+illum 2
+newmtl unused
+Kd 0 0 1
+newmtl green_gloss
+Kd 0.1 0.7 0.2
+Ks 0.4 0.4 0.4
+Ns 90
+Ni 1.3
+illum 2
+newmtl mirror_blue
+Kd 0.05 0.05 0.3
+Ks 0.7 0.7 0.8
+Ns 300
+illum 3
+"""
+    return "\n".join(lines) + "\n", mtl
+
+
+def multi_material_scene_xml(obj_name="multi.obj", width=96, height=54):
+    """The object above (no material attribute: its node gets the OBJ file's materials) over a floor, one sphere."""
+    return f"""<xml>
+  <scene>
+    <object type="obj" name="{obj_name}"><translate z="2"/></object>
+    <object type="plane" name="floor" material="floor"><scale value="40"/><translate z="-3"/></object>
+    <object type="sphere" name="ball" material="ball"><scale value="2"/><translate x="5" y="-3" z="5"/></object>
+    <material type="blinn" name="floor"><diffuse value="0.7"/><specular value="0"/></material>
+    <material type="blinn" name="ball"><diffuse r="0.7" g="0.6" b="0.2"/><specular value="0.3"/><glossiness value="50"/></material>
+    <light type="point" name="lamp"><intensity value="1200"/><position x="2" y="-6" z="25"/><size value="1"/></light>
+    <background value="0.1"/>
+  </scene>
+  <camera gamma="sRGB">
+    <position x="0" y="-26" z="14"/>
+    <target x="0" y="0" z="1"/>
+    <up x="0" y="0" z="1"/>
+    <fov value="40"/>
+    <width value="{width}"/>
+    <height value="{height}"/>
+  </camera>
+</xml>
+"""

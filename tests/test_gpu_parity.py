@@ -543,3 +543,51 @@ def test_textured_images_vs_reference(ctx, name, tmp_path):
     bad.background_texture = 99
     with pytest.raises(lib.RtError):
         ctx.upload(bad)
+
+
+def test_multi_material_object_vs_reference(ctx, tmp_path, monkeypatch):
+    """An OBJ object that brings its own materials (the reference's MultiMtl).  As the reference renders it - every face
+    with the first member - against the snapshot's image; with face_materials (each face with the member it names)
+    against the CPU oracle, in both renderers and through both pipelines of the path tracer.  A PNG texture on one
+    member's diffuse colour (the library's `map_Kd`) travels the same way."""
+    from test_host_side import multi_material_scene
+    from raytracer_amd import scenes
+    g = O.load_golden("whitted_multimtl_96x54_b5")
+    hs = multi_material_scene(g, tmp_path)
+    seed, mn, mx, w, h, bounces = [int(x) for x in g["params"]]
+    prm = abi.default_params(seed=seed, min_spp=mn, max_spp=mx, delta_max=float(g["delta"]), max_bounces=bounces, mode=abi.RT_MODE_WHITTED)
+    fr = render_gpu(ctx, hs, prm, w, h)
+    assert np.array_equal(fr.object_id, g["object_id"]), "primary-hit ids"
+    assert np.array_equal(bits(fr.z), bits(g["z"])), "z-buffer"
+    p = O.psnr(fr.rgb, g["rgb"])
+    assert p >= PSNR_MIN, f"PSNR {p:.2f} dB vs the reference image"
+
+    # a texture on the second member, and every face with its own member
+    (tmp_path / "multi.mtl").write_bytes(bytes(g["mtl"]).replace(b"Ns 90\n", b"Ns 90\nmap_Kd leaf.png\n"))
+    (tmp_path / "leaf.png").write_bytes(scenes.png_bytes(scenes.texture_image(), 2, 8))
+    hs = lib.HostScene.from_string(bytes(g["xml"]).decode(), str(tmp_path))
+    assert hs.warnings() == [] and hs.desc.materials[3].diffuse_texture > 0
+    hs.set_face_materials(True)
+    cpu = O.render(hs, prm, w, h)
+    gpu = render_gpu(ctx, hs, prm, w, h)
+    assert np.array_equal(gpu.object_id, cpu.object_id) and np.array_equal(bits(gpu.z), bits(cpu.z))
+    p = O.psnr(gpu.rgb, cpu.rgb)
+    assert p >= PSNR_MIN, f"Whitted-style shader, per-face members: PSNR {p:.2f} dB vs the oracle"
+    assert np.abs(gpu.linear - fr.linear).max(axis=2)[g["object_id"] == 1].mean() > 0.02  # not the first member's picture
+    pt = abi.default_params(seed=seed, min_spp=16, max_spp=16)
+    cpu = O.render(hs, pt, w, h)
+    for pipe in ("wave", "mega"):
+        monkeypatch.setenv("RT_PIPELINE", pipe)
+        c2 = lib.Context(0)
+        try:
+            gpu = render_gpu(c2, hs, pt, w, h)
+        finally:
+            c2.close()
+        assert np.array_equal(gpu.object_id, cpu.object_id) and np.array_equal(bits(gpu.z), bits(cpu.z))
+        p = O.psnr(gpu.rgb, cpu.rgb)
+        assert p >= PSNR_MIN, f"path tracer ({pipe}), per-face members: PSNR {p:.2f} dB vs the oracle"
+    # a face that names a member past the materials the node brings is refused
+    bad = abi.SceneDesc.from_buffer_copy(hs.desc)
+    bad.n_materials -= 1
+    with pytest.raises(lib.RtError):
+        ctx.upload(bad)

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(lib.SYMBOLS)
     for name in declared:
         assert hasattr(L, name), name
-    assert L.rt_abi_version() == 4
+    assert L.rt_abi_version() == 5
 
 
 def test_struct_sizes_match_header(tmp_path):
@@ -36,7 +36,7 @@ def test_struct_sizes_match_header(tmp_path):
     pairs = {"rt_node": abi.Node, "rt_bvh_node": abi.BvhNode, "rt_material": abi.Material, "rt_light": abi.Light,
              "rt_hit": abi.Hit, "rt_hit_brief": abi.HitBrief, "rt_render_params": abi.RenderParams, "rt_camera": abi.Camera,
              "rt_frame_out": abi.FrameOut, "rt_counters": abi.Counters, "rt_photon_params": abi.PhotonParams, "rt_progress_info": abi.ProgressInfo,
-             "rt_scene_desc": abi.SceneDesc}
+             "rt_scene_desc": abi.SceneDesc, "rt_mesh": abi.Mesh, "rt_texture": abi.Texture}
     src = "#include <stdio.h>\n#include \"rt_mi355x.h\"\nint main(void){\n"
     src += "".join(f'printf("{n} %zu\\n", sizeof({n}));\n' for n in pairs)
     src += 'printf("rt_photon %zu\\n", sizeof(rt_photon)); return 0; }\n'
@@ -132,6 +132,73 @@ def test_mesh_scene_from_arrays():
     assert hs.desc.meshes[0].nf == 0  # file absent: mesh stays empty until set
     hs.set_mesh("mesh_small.obj", mesh["v"], mesh["vt"], mesh["f"])
     check_mesh(hs.desc.meshes[0], g)
+
+
+def multi_material_scene(g, tmp_path):
+    """The fixture's OBJ file, material library and scene text, through our own loader."""
+    (tmp_path / "multi.obj").write_bytes(bytes(g["obj"]))
+    (tmp_path / "multi.mtl").write_bytes(bytes(g["mtl"]))
+    return lib.HostScene.from_string(bytes(g["xml"]).decode(), str(tmp_path))
+
+
+def test_obj_with_materials_matches_reference_loader(tmp_path):
+    """An OBJ file with `usemtl` groups and a material library, on a node without a material attribute: the reference
+    regroups the faces by material and gives the node a MultiMtl made of the library's entries (xmlload.cpp:157,278-322).
+    Our loader's faces, BVH, sub-material per face and the members' constants against the reference's dump."""
+    g = O.load_golden("whitted_multimtl_96x54_b5")
+    hs = multi_material_scene(g, tmp_path)
+    check_scene_against_dump(hs, g)  # the members follow the scene file's materials; the node names the first
+    m = hs.desc.meshes[0]
+    check_mesh(m, g)
+    assert m.n_sub_materials == 3 == int(g["scene_material_members"][2])
+    fm = np.ctypeslib.as_array(m.face_material, (m.nf,))
+    assert np.array_equal(fm, g["scene_mesh0_face_material"])
+    assert set(fm) == {0, 1, 2} and np.all(np.diff(fm.astype(int)) >= 0)  # grouped: every material's faces are consecutive
+    assert hs.desc.face_materials == 0  # as the reference renders: every face with the first member
+    assert hs.warnings() == []
+
+
+def test_png_decoder_matches_reference_decoder():
+    """PNG files of every colour type and bit depth, plain and interlaced, all five filter types: the pixels our decoder
+    delivers against those of the reference's decoder called as its texture loader calls it (texture.cpp:77-87)."""
+    g = O.load_golden("png_cases")
+    names = [k[5:] for k in g if k.startswith("file_")]
+    assert len(names) == 32
+    for n in names:
+        got = lib.png_decode(g["file_" + n].tobytes())
+        assert got.shape == g["rgb_" + n].shape and np.array_equal(got, g["rgb_" + n]), n
+    # the generator in the repository still writes the very files the fixture holds
+    cases = scenes.png_cases()
+    assert all(cases[n] == g["file_" + n].tobytes() for n in names)
+    # damaged files are refused, not decoded
+    good = bytearray(g["file_c2_d8_plain"].tobytes())
+    for cut in (0, 7, 20, len(good) // 2, len(good) - 13):
+        with pytest.raises(lib.RtError):
+            lib.png_decode(bytes(good[:cut]))
+    bad = bytearray(good)
+    bad[len(bad) // 2] ^= 0x40  # inside the image data: chunk checksum
+    with pytest.raises(lib.RtError):
+        lib.png_decode(bytes(bad))
+
+
+def test_png_texture_file(tmp_path):
+    """A texture named *.png reaches the scene with the pixels of the same image as a PPM file; a name that is neither
+    is reported and ignored, as the reference does (texture.cpp:70-95)."""
+    g = O.load_golden("image_textured_96x54_s8")
+    img = g["image"]
+    h, w, _ = img.shape
+    (tmp_path / "tex.PNG").write_bytes(scenes.png_bytes(img, 2, 8, interlace=True))
+    hs = lib.HostScene.from_string(scenes.textured_scene_xml("tex.PNG", 96, 54), str(tmp_path))
+    d = hs.desc
+    images = [d.textures[i] for i in range(d.n_textures) if d.textures[i].type == abi.RT_TEX_IMAGE]
+    assert len(images) == 2  # the sphere's diffuse colour and the environment
+    for tx in images:
+        assert (tx.width, tx.height) == (w, h)
+        assert np.array_equal(np.ctypeslib.as_array(tx.pixels, shape=(h, w, 3)), img)
+    assert hs.warnings() == []
+    hs2 = lib.HostScene.from_string(scenes.textured_scene_xml("tex.gif", 96, 54), str(tmp_path))
+    assert sum(hs2.desc.textures[i].type == abi.RT_TEX_IMAGE for i in range(hs2.desc.n_textures)) == 0
+    assert any("tex.gif" in x for x in hs2.warnings())
 
 
 def test_bvh_build_entry_point():

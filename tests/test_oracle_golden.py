@@ -323,3 +323,32 @@ def test_textures(name, tmp_path):
     assert_bits_equal(fr.linear, g["linear"], "linear radiance")
     assert np.array_equal(fr.rgb, g["rgb"]), "8-bit image"
     assert (g["object_id"] == -1).mean() > 0.05  # the background is in the picture
+
+
+def test_multi_material_object(tmp_path):
+    """An OBJ object with its own materials (a MultiMtl in the reference) rendered by the snapshot's shader: every face
+    is shaded with the first member, because no intersector sets HitInfo::mtlID - bit for bit.  With face_materials the
+    faces take the members they name: a different picture on the object, the same everywhere else."""
+    from test_host_side import multi_material_scene
+    g = O.load_golden("whitted_multimtl_96x54_b5")
+    hs = multi_material_scene(g, tmp_path)
+    seed, mn, mx, w, h, bounces = [int(x) for x in g["params"]]
+    prm = abi.default_params(seed=seed, min_spp=mn, max_spp=mx, delta_max=float(g["delta"]), max_bounces=bounces, mode=abi.RT_MODE_WHITTED)
+    fr = O.render(hs, prm, w, h)
+    assert np.array_equal(fr.object_id, g["object_id"]), "primary-hit ids"
+    assert_bits_equal(fr.z, g["z"], "z-buffer")
+    assert_bits_equal(fr.linear, g["linear"], "linear radiance")
+    assert np.array_equal(fr.rgb, g["rgb"]), "8-bit image"
+    on_object = g["object_id"] == 1
+    assert on_object.mean() > 0.05
+    hs.set_face_materials(True)
+    per_face = O.render(hs, prm, w, h)
+    assert np.array_equal(per_face.object_id, g["object_id"])
+    diff = np.abs(per_face.linear - fr.linear).max(axis=2)
+    assert (diff[on_object] > 0.02).mean() > 0.3  # two thirds of the faces name another member
+    for mode in (abi.RT_MODE_PATH,):  # the path tracer picks members the same way
+        p2 = abi.default_params(seed=seed, min_spp=8, max_spp=8, mode=mode)
+        a = O.render(hs, p2, w, h)
+        hs.set_face_materials(False)
+        b = O.render(hs, p2, w, h)
+        assert (np.abs(a.linear - b.linear).max(axis=2)[on_object] > 0.02).mean() > 0.3
