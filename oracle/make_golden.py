@@ -11,6 +11,7 @@ reference source text.
     python oracle/make_golden.py --whitted  # only the project-12 (Whitted-style shader) fixtures
     python oracle/make_golden.py --photons  # only the photon-map fixtures
     python oracle/make_golden.py --config-c       # only the full-size 1M-triangle band and ray fixture
+    python oracle/make_golden.py --config-e       # only the full-size 10M-triangle band and ray fixture (minutes)
     python oracle/make_golden.py --photons-large  # only the tall photon map
     python oracle/make_golden.py --png            # only the PNG decoding cases
     python oracle/make_golden.py --multimtl       # only the OBJ-with-materials scene
@@ -161,6 +162,35 @@ def config_c():
         save("config_c_1m", **common, params=np.array([7, 4, 4, 1920, 1080, y0, y1], np.int64), delta=np.float32(0.01), **band, **kat)
 
 
+def config_e():
+    """The 10M-triangle configuration at its full size (5000 x 1000 quads, BVH depth 29, 3840x2160, 16..256 samples with
+    the variance stop): digests of the reference's mesh arrays and BVH, a 16-row band of the frame through every object
+    and rays aimed at the mesh, as config_c()."""
+    import hashlib
+    with tempfile.TemporaryDirectory() as tmp:
+        mesh = scenes.heightfield(5000, 1000)
+        scenes.write_obj(os.path.join(tmp, "mesh_10m.obj"), mesh)
+        xml = scenes.mesh_scene_xml("mesh_10m.obj", 3840, 2160)
+        p = os.path.join(tmp, "scene.xml")
+        open(p, "w").write(xml)
+        sc = scene_bundle(p, cwd=tmp)
+        digests, small = {}, {}
+        for k, v in sc.items():
+            if k.startswith("scene_mesh0_"):
+                if k.endswith("bvh_nodes"):
+                    v = v[1:]
+                digests[k.replace("scene_", "sha256_")] = np.frombuffer(hashlib.sha256(np.ascontiguousarray(v).tobytes()).digest(), np.uint8)
+                small["count_" + k[len("scene_"):]] = np.int64(len(v))
+            else:
+                small[k] = v
+        del sc
+        common = dict(xml=np.frombuffer(xml.encode(), np.uint8), mesh_nx=np.int32(5000), mesh_ny=np.int32(1000), **small, **digests)
+        y0, y1 = 832, 848
+        band = run(p, "render", 7, 16, 256, 0.01, 3840, 2160, y0, y1, cwd=tmp)
+        kat = run(p, "kat_trace", 4096, 37, 40, 1, cwd=tmp)
+        save("config_e_10m", **common, params=np.array([7, 16, 256, 3840, 2160, y0, y1], np.int64), delta=np.float32(0.01), **band, **kat)
+
+
 def photons_large():
     """A photon map tall enough (>= 32768 photons: 16 levels) that the kd-tree walk of a lookup leaves the levels the
     GPU keeps in fast memory; otherwise as photons()."""
@@ -209,6 +239,8 @@ def multi_material():
 
 def main():
     os.makedirs(GOLD, exist_ok=True)
+    if "--config-e" in sys.argv:
+        return config_e()
     if "--png" in sys.argv:
         return png()
     if "--multimtl" in sys.argv:
@@ -276,6 +308,7 @@ def main():
     textures()
     config_c()
     photons_large()
+    config_e()
     png()
     multi_material()
 

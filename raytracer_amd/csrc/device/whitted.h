@@ -22,7 +22,7 @@ namespace rtd {
 #define RT_GATHER_QUORUM 64 // measured on the photon-box frame: 16 / 32 / 48 / 64 lanes -> 4.04 / 3.56 / 3.11 / 2.99 s
 #endif
 #ifndef RT_WHITTED_MIN_WAVES
-#define RT_WHITTED_MIN_WAVES 4 // waves per SIMD the register allocator must leave room for
+#define RT_WHITTED_MIN_WAVES 3 // waves per SIMD the register allocator must leave room for: 170 registers; at 4 (128 registers) the kernel spills 220 values and is 5 % slower on both Whitted workloads, at 2 it is 18 % slower
 #endif
 #ifndef RT_WHITTED_CULL
 #define RT_WHITTED_CULL 1 // skip objects whose world-space box no ray of the wave reaches (trace_closest / trace_shadow); 0 builds the votes out

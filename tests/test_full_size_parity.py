@@ -4,6 +4,8 @@
     object, and 8192 rays aimed at the mesh, both answered by the reference (oracle/make_golden.py --config-c).  The
     scene is rebuilt here from the generated height field; SHA-256 digests of the reference's own mesh arrays, computed
     normals and BVH pin the library's OBJ arrays, normal computation and BVH builder at this size.
+  * config_e_10m: the 10M-triangle scene (BVH depth 29) at 3840x2160 with 16..256 samples and the variance stop - the
+    same checks (oracle/make_golden.py --config-e): digests of the reference's arrays, a 16-row band, 4096 aimed rays.
   * photons_a_large: photon maps of 36 000 + 17 000 photons (kd-trees 16 and 15 levels tall).
   * every GPU check also runs in a context whose lanes keep only three stack levels in LDS (RT_LDS_LEVELS=3), so the
     global overflow levels of the BVH stack and of the kd-tree stack are executed against reference answers.
@@ -42,9 +44,21 @@ def scene_c():
     return _scene_c["hs"], _scene_c["g"]
 
 
-# ---------------------------------------------------------------- CPU: scene and oracle against the reference
-def test_config_c_scene_equals_the_references():
-    hs, g = scene_c()
+def scene_e():
+    """The 10M-triangle scene the same way (about eight seconds, 1.3 GB of host arrays; built once)."""
+    if "hs" not in _scene_e:
+        g = O.load_golden("config_e_10m")
+        mesh = scenes.heightfield(int(g["mesh_nx"]), int(g["mesh_ny"]))
+        hs = lib.HostScene.from_string(bytes(g["xml"]).decode())
+        hs.set_mesh("mesh_10m.obj", mesh["v"], mesh["vt"], mesh["f"])
+        _scene_e["hs"], _scene_e["g"] = hs, g
+    return _scene_e["hs"], _scene_e["g"]
+
+
+_scene_e = {}
+
+
+def check_mesh_digests(hs, g):
     check_scene_against_dump(hs, g)
     m = hs.desc.meshes[0]
     a = mesh_arrays(m)
@@ -53,7 +67,41 @@ def test_config_c_scene_equals_the_references():
         assert len(arr) == int(g["count_mesh0_" + k]), k
         got = np.frombuffer(hashlib.sha256(np.ascontiguousarray(arr).tobytes()).digest(), np.uint8)
         assert np.array_equal(got, g["sha256_mesh0_" + k]), f"{k} differs from the reference's array"
+    return m
+
+
+# ---------------------------------------------------------------- CPU: scene and oracle against the reference
+def test_config_c_scene_equals_the_references():
+    hs, g = scene_c()
+    m = check_mesh_digests(hs, g)
     assert m.nf == 1_000_000 and m.bvh_depth == 24
+
+
+def test_config_e_scene_equals_the_references():
+    hs, g = scene_e()
+    m = check_mesh_digests(hs, g)
+    assert m.nf == 10_000_000 and m.bvh_depth == 29
+
+
+def test_config_e_oracle_band_and_rays():
+    """Adaptive sampling at full size: the variance stop decides every pixel's sample count (16..256)."""
+    hs, g = scene_e()
+    seed, mn, mx, w, h, y0, y1 = [int(x) for x in g["params"]]
+    assert (mn, mx, w, h) == (16, 256, 3840, 2160)
+    prm = abi.default_params(seed=seed, min_spp=mn, max_spp=mx, delta_max=float(g["delta"]))
+    fr = O.render(hs, prm, w, h, y0=y0, y1=y1, fast=False)
+    assert set(np.unique(g["object_id"])) == {1, 2, 3, 4}
+    assert len(np.unique(g["sample_count"])) > 20 and g["sample_count"].min() == 16 and g["sample_count"].max() == 256
+    assert np.array_equal(fr.object_id[y0:y1], g["object_id"]), "primary-hit ids"
+    assert np.array_equal(bits(fr.z[y0:y1]), bits(g["z"])), "z-buffer"
+    assert np.array_equal(fr.sample_count[y0:y1], g["sample_count"]), "sample counts"
+    assert np.array_equal(bits(fr.linear[y0:y1]), bits(g["linear"])), "linear radiance"
+    assert np.array_equal(fr.rgb[y0:y1], g["rgb"]), "8-bit image"
+    n = 1024
+    hits = O.trace(hs, g["kat_rays"][:n])
+    assert np.array_equal(hits["node"], g["kat_id"][:n])
+    assert np.array_equal(bits(hits["z"]), bits(g["kat_hit"][:n, 0]))
+    assert np.array_equal(O.trace_shadow(hs, g["kat_rays"][:n], g["kat_tmax"][:n]), g["kat_flags"][:n, 2])
 
 
 def test_config_c_oracle_band():
@@ -152,6 +200,34 @@ def test_config_c_band_vs_reference(ctx):
     assert p >= PSNR_MIN, f"PSNR {p:.2f} dB vs the reference's band"
     close = np.all(np.abs(fr.linear[y0:y1] - g["linear"]) <= 1e-4 * np.maximum(1.0, np.abs(g["linear"])), axis=-1)
     assert close.mean() >= 0.97, f"only {close.mean():.4f} of the pixels agree in linear radiance"
+
+
+@pytest.mark.gpu
+def test_config_e_vs_reference(ctx):
+    """The 10M-triangle scene at 3840x2160 with 16..256 adaptive samples: aimed rays bit for bit, and rows 832..847 of
+    the whole frame (ids, z; sample counts and image within the tolerance of the adaptive goldens)."""
+    hs, g = scene_e()
+    seed, mn, mx, w, h, y0, y1 = [int(x) for x in g["params"]]
+    ctx.upload(hs.desc)
+    hits = ctx.trace(g["kat_rays"])
+    ref_hit = g["kat_flags"][:, 0].astype(bool)
+    assert (g["kat_id"] == 1).sum() > 3000
+    assert np.array_equal(hits["node"], g["kat_id"]), "hit node ids"
+    assert np.array_equal(bits(hits["z"]), bits(g["kat_hit"][:, 0])), "z"
+    on_obj = ref_hit & (g["kat_id"] >= 0)
+    assert np.array_equal(bits(hits["p"][on_obj]), bits(g["kat_hit"][on_obj, 1:4])), "hit point"
+    assert np.array_equal(bits(hits["n"][on_obj]), bits(g["kat_hit"][on_obj, 4:7])), "normal"
+    assert np.array_equal(ctx.trace_shadow(g["kat_rays"], g["kat_tmax"]), g["kat_flags"][:, 2]), "shadow rays"
+    brief = ctx.trace_brief(g["kat_rays"])
+    assert np.array_equal(brief["node"], g["kat_id"]) and np.array_equal(bits(brief["t"]), bits(g["kat_hit"][:, 0]))
+    ctx.set_camera(hs.camera, w, h)
+    fr = ctx.render(abi.default_params(seed=seed, min_spp=mn, max_spp=mx, delta_max=float(g["delta"])))
+    assert np.array_equal(fr.object_id[y0:y1], g["object_id"]), "primary-hit ids"
+    assert np.array_equal(bits(fr.z[y0:y1]), bits(g["z"])), "z-buffer"
+    same = (fr.sample_count[y0:y1] == g["sample_count"]).mean()
+    assert same >= 0.97, f"sample counts equal in {same:.4f} of the band's pixels"  # a last-ulp difference in one sample can move the stop
+    p = O.psnr(fr.rgb[y0:y1], g["rgb"])
+    assert p >= PSNR_MIN, f"PSNR {p:.2f} dB vs the reference's band"
 
 
 @pytest.mark.gpu
