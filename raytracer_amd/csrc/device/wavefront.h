@@ -127,36 +127,177 @@ __global__ __launch_bounds__(kBlock) void k_planes(DScene S, DFrame F, const flo
     }
 }
 
+// What a path does at a surface vertex (src/main.cpp:212-264), with the shadow ray left for later: the next-event
+// sample and the contribution its shadow ray gates (worked out now, with this vertex' throughput), then the
+// material's sample.  Returns whether the path goes on (new_o / new_d / thr then describe the next extension ray).
+struct VertexRays {
+    float4 s_o, s_d, s_c;  // shadow ray: origin + t_max, direction, the contribution it gates
+    float4 new_o, new_d;   // next extension ray in the slot layout of WfState
+};
+RT_DEV bool surface_vertex(const DScene &S, const DFrame &F, const rt_light &light, const Ray &ray, Hit &h, V3 &thr, int bounce,
+                           Rng &rng, VertexRays &o)
+{
+    finish_hit(S, ray, h, false);
+    Surface s; // SamplerInfo::SetHit (renderer.h:145-153)
+    const V3 normal = normalize(h.n);
+    s.p = h.p; s.n = normal; s.v = -normalize(ray.d); s.front = h.front;
+    const rt_material &mtl = S.materials[hit_material(S, h.node, h.face)];
+    // next-event estimation (main.cpp:214-251): the shadow ray is always sent, as in the reference
+    Sample ne;
+    light_generate(light, s.p, rng, ne);
+    const float sgn = h.front ? 1.0f : -1.0f;
+    const V3 so = h.p + (normal * F.bias) * sgn;
+    V3 c = mk(0.0f, 0.0f, 0.0f);
+    const float cosS = std_max(0.0f, dot(normal, ne.dir));
+    if (cosS > 0.0f && ne.prob > 0.0f) {
+        const float mp = mtl_pdf(mtl, s, ne.dir);
+        float weight = 1.0f;
+        if (mp > 0.0f) weight = (ne.prob * ne.prob) / (ne.prob * ne.prob + mp * mp);
+        // the specular term of main.cpp:241-246 is gated on a field GetSampleInfo never writes: diffuse only
+        const V3 brdf = ld3(mtl.diffuse) / kPi;
+        c = ((((brdf * cosS) * ne.mult) * weight) / ne.prob) * thr;
+    }
+    o.s_o = make_float4(so.x, so.y, so.z, ne.dist - F.bias);
+    o.s_d = make_float4(ne.dir.x, ne.dir.y, ne.dir.z, 0.0f);
+    o.s_c = make_float4(c.x, c.y, c.z, 0.0f);
+    // indirect bounce (main.cpp:253-264)
+    Sample in;
+    if (!(mtl_generate(mtl, s, rng, in) && bounce + 1 < F.max_bounces)) return false;
+    const float sg = (dot(normal, in.dir) > 0.0f) ? 1.0f : -1.0f;
+    const V3 no = h.p + (normal * F.bias) * sg;
+    thr = thr * (in.mult / in.prob);
+    o.new_o = make_float4(no.x, no.y, no.z, in.prob);
+    o.new_d = make_float4(in.dir.x, in.dir.y, in.dir.z, __uint_as_float((uint32_t)(bounce + 1) | ((uint32_t)in.lobe << 16)));
+    return true;
+}
+
+// A ray whose answer stays with the lane that traced it (k_wf_finish): nothing is fetched, nothing stored.
+struct LaneIO {
+    static constexpr bool kWide = true;
+    static constexpr bool kDeferShadow = true; // the kernel reads RayWalker::unoccluded itself
+    typedef NoPending Pending;
+    Hit *h;
+    RT_DEV void begin_put_shadow(uint32_t, Pending &) const {}
+    RT_DEV void end_put_shadow(uint32_t, const Pending &) const {}
+    RT_DEV void put_shadow(uint32_t, bool) const {}
+    RT_DEV void put_closest(uint32_t, float t, int node, uint32_t face, int front, float u, float v) const
+    {
+        h->z = t; h->node = node; h->face = face; h->front = front; h->u = u; h->v = v;
+    }
+};
+
 // The last of a round's paths, to their ends in one launch.  After a few bounces a handful of paths is left (glass,
-// mirrors), and a bounce of the pipeline - a ray launch for a thousand rays, a shading launch, the host reading the
-// counts - takes 0.2 ms however few they are: forty more of those are 8 to 10 ms, a third of a frame's time on one
-// eighth of the image.  Here a lane takes one live path and runs tracePath's loop on it (path_step, the lock-step
-// kernel's own code, binary BVH walk) until it ends.
+// mirrors, valleys of a mesh), and a bounce of the pipeline - a ray launch for a thousand rays, a shading launch, the
+// host reading the counts - takes 0.2 ms however few they are: forty more of those are 8 to 10 ms, a third of a
+// frame's time on one eighth of the image.  What is left then is a chain of dependent steps - the longest path's
+// bounces, each a closest-hit walk, a shadow walk and the shading between them - on a nearly idle chip, so this
+// kernel is built for the length of that chain, not for throughput: a path belongs to a PAIR of lanes.  The even
+// lane keeps the path and traces its extension rays; the odd lane traces the shadow ray of the vertex before, at the
+// same time (the next direction does not depend on the shadow ray's answer, only the sum does, and that is added in
+// the path's own order: next-event term of vertex b, then whatever vertex b + 1 adds).  Both walk through the ray-list
+// kernel's walker (four-wide BVH, one step of one ray as the unit), so a bounce costs one walk's worth of dependent
+// fetches instead of two binary ones.  A pair whose path has ended takes the next one from the list.
 template <bool COUNT, int LEVELS>
 __global__ __launch_bounds__(kBlock) void k_wf_finish(DScene S, DFrame F, int k0, int nk, WfState P,
-                                                      const uint32_t *__restrict__ queue_in, uint32_t n_in, DCounters *ctr)
+                                                      const uint32_t *__restrict__ queue_in, uint32_t n_in, DCounters *ctr,
+                                                      unsigned long long *queue)
 {
     extern __shared__ uint32_t lds[];
     const LaneStack st = lane_stack(lds, S);
+    const rt_light &light = S.lights[0];
+    const uint32_t lane = threadIdx.x & 63u;
+    const bool keeper = (lane & 1u) == 0; // even lane: the path and its extension rays; odd lane: its shadow rays
+    const int even = (int)(lane & ~1u), odd = (int)(lane | 1u);
     PathTally pt;
     Tally<COUNT> tl;
-    for (uint32_t e = blockIdx.x * kBlock + threadIdx.x; e < n_in; e += gridDim.x * kBlock) {
-        const uint32_t slot = queue_in[e];
-        const float4 ro = P.ray_o[slot], rd = P.ray_d[slot], t = P.thr[slot], a = P.acc[slot];
-        const uint2 rs = P.rng[slot];
-        const int k = k0 + (int)(slot % (uint32_t)nk);
-        const uint32_t bits = __float_as_uint(rd.w);
-        PathState ps;
-        ps.ray = Ray{mk(ro.x, ro.y, ro.z), mk(rd.x, rd.y, rd.z)};
-        ps.throughput = mk(t.x, t.y, t.z);
-        ps.result = mk(a.x, a.y, a.z);
-        ps.rng.state = ((uint64_t)rs.y << 32) | rs.x;
-        ps.rng.inc = (((uint64_t)k + 1) << 1u) | 1u;
-        ps.lastProb = ro.w;
-        ps.lastLobe = (int)(bits >> 16);
-        ps.bounce = (int)(bits & 0xFFFFu);
-        while (path_step<COUNT, LEVELS, true>(S, F, ps, st, pt, tl, nullptr, nullptr)) {}
-        P.acc[slot] = make_float4(ps.result.x, ps.result.y, ps.result.z, a.w);
+    Hit h;
+    h.z = FLT_MAX; h.node = -1; h.face = 0; h.front = 1; h.u = 0; h.v = 0;
+    const LaneIO io{&h};
+    RayWalker<COUNT, LEVELS, LaneIO> w;
+    // the keeper's path
+    bool have_path = false, goes_on = false, owes_shadow = false;
+    uint32_t slot = 0;
+    Ray ray{mk(0, 0, 0), mk(0, 0, 1)};
+    V3 thr = mk(0, 0, 0), result = mk(0, 0, 0);
+    float acc_w = 0.0f, lastProb = 1.0f;
+    int lastLobe = LOBE_NONE, bounce = 0;
+    Rng rng;
+    rng.state = 0; rng.inc = 1;
+    VertexRays vr;
+    vr.s_o = vr.s_d = vr.s_c = vr.new_o = vr.new_d = make_float4(0, 0, 0, 0);
+    bool exhausted = false;
+    pt.tick();
+    for (;;) {
+        // ---- pairs without a path take the next ones of the list (one atomic per wave) ----
+        const uint64_t free_pairs = __ballot(keeper && !have_path);
+        if (free_pairs != 0 && !exhausted) {
+            const uint32_t want = (uint32_t)__popcll(free_pairs);
+            unsigned long long b = 0;
+            if (lane == 0) b = atomicAdd(queue, (unsigned long long)want);
+            b = __shfl(b, 0, 64);
+            const uint32_t rank = (uint32_t)__popcll(free_pairs & ((1ull << lane) - 1ull));
+            if (b + want >= n_in) exhausted = true;
+            if (keeper && !have_path && b + rank < n_in) {
+                slot = queue_in[b + rank];
+                const float4 ro = P.ray_o[slot], rd = P.ray_d[slot], t = P.thr[slot], a = P.acc[slot];
+                const uint2 rs = P.rng[slot];
+                const int k = k0 + (int)(slot % (uint32_t)nk);
+                const uint32_t bits = __float_as_uint(rd.w);
+                ray = Ray{mk(ro.x, ro.y, ro.z), mk(rd.x, rd.y, rd.z)};
+                thr = mk(t.x, t.y, t.z);
+                result = mk(a.x, a.y, a.z); acc_w = a.w;
+                rng.state = ((uint64_t)rs.y << 32) | rs.x;
+                rng.inc = (((uint64_t)k + 1) << 1u) | 1u;
+                lastProb = ro.w; lastLobe = (int)(bits >> 16); bounce = (int)(bits & 0xFFFFu);
+                have_path = true; goes_on = true; owes_shadow = false;
+            }
+        }
+        // ---- this trip's rays: the path's extension ray on the even lane, the last vertex' shadow ray on the odd one ----
+        const bool sh = __shfl((int)(keeper && owes_shadow), even, 64) != 0;
+        const float4 so = make_float4(__shfl(vr.s_o.x, even, 64), __shfl(vr.s_o.y, even, 64), __shfl(vr.s_o.z, even, 64), __shfl(vr.s_o.w, even, 64));
+        const float4 sd = make_float4(__shfl(vr.s_d.x, even, 64), __shfl(vr.s_d.y, even, 64), __shfl(vr.s_d.z, even, 64), 0.0f);
+        if (keeper && have_path && goes_on) w.start(slot, make_float4(ray.p.x, ray.p.y, ray.p.z, 0.0f), make_float4(ray.d.x, ray.d.y, ray.d.z, 0.0f), false, 0.0f, pt);
+        if (!keeper && sh) w.start(0, so, sd, true, so.w, pt);
+        if (!__any(w.active)) break; // no pair has a path left, and the list is empty
+        while (__any(w.active)) w.phases(S, io, st, nullptr, pt, tl);
+        // ---- the shadow ray's answer first (vertex b), then the new vertex (b + 1) ----
+        const bool lit = __shfl((int)(!keeper && w.unoccluded), odd, 64) != 0;
+        w.unoccluded = false;
+        if (keeper && owes_shadow) {
+            if (lit) result = result + mk(vr.s_c.x, vr.s_c.y, vr.s_c.z);
+            owes_shadow = false;
+        }
+        if (keeper && have_path && goes_on) {
+            w.finish_closest(S, io); // the lights, then the answer into h
+            goes_on = false;
+            if (h.node == -1) { // main.cpp:175-176
+                result = result + textured_color(S, S.background, S.background_texture, ray.d) * thr;
+            } else if (h.node < 0) { // light (main.cpp:184-210)
+                const V3 rad = light_radiance(light);
+                if (bounce == 0) result = result + rad * thr;
+                else {
+                    float weight = 1.0f;
+                    if (lastLobe == LOBE_DIFFUSE) {
+                        const float lp = light_pdf(light, ray.p, ray.d);
+                        if (lp > 0.0f) weight = (lastProb * lastProb) / (lastProb * lastProb + lp * lp);
+                    }
+                    result = result + (rad * thr) * weight;
+                }
+            } else {
+                goes_on = surface_vertex(S, F, light, ray, h, thr, bounce, rng, vr);
+                owes_shadow = true;
+                if (goes_on) {
+                    ray = Ray{mk(vr.new_o.x, vr.new_o.y, vr.new_o.z), mk(vr.new_d.x, vr.new_d.y, vr.new_d.z)};
+                    lastProb = vr.new_o.w;
+                    const uint32_t bits = __float_as_uint(vr.new_d.w);
+                    bounce = (int)(bits & 0xFFFFu); lastLobe = (int)(bits >> 16);
+                }
+            }
+        }
+        if (keeper && have_path && !goes_on && !owes_shadow) { // the path's radiance is complete
+            P.acc[slot] = make_float4(result.x, result.y, result.z, acc_w);
+            have_path = false;
+        }
     }
     flush_counters<COUNT>(ctr, pt, tl, 0);
 }
@@ -286,6 +427,7 @@ __global__ __launch_bounds__(kBlock) void k_wf_shade(DScene S, DFrame F, const i
                     rng.state = ((uint64_t)rs.y << 32) | rs.x;
                     rng.inc = (((uint64_t)k + 1) << 1u) | 1u;
                 }
+                // (the arithmetic of surface_vertex, kept in line: through the call this kernel came out 10 % slower)
                 finish_hit(S, ray, h, false);
                 Surface s; // SamplerInfo::SetHit (renderer.h:145-153)
                 const V3 normal = normalize(h.n);

@@ -320,11 +320,13 @@ static int render_wavefront(rt_ctx *ctx, const DFrame &F, const int32_t *act, ui
         if (finishing) { // the shadow rays of the last shaded bounce are in; the remaining paths run to their ends in one launch
             const void *ff = ctx->counting ? (ctx->ray_levels <= 1 ? (const void *)k_wf_finish<true, 1> : ctx->ray_levels == 2 ? (const void *)k_wf_finish<true, 2> : (const void *)k_wf_finish<true, 5>)
                                            : (ctx->ray_levels <= 1 ? (const void *)k_wf_finish<false, 1> : ctx->ray_levels == 2 ? (const void *)k_wf_finish<false, 2> : (const void *)k_wf_finish<false, 5>);
-            const dim3 grid((unsigned)std::min<uint64_t>(((uint64_t)n_ext + kBlock - 1) / kBlock, ctx->ovf_threads / kBlock));
+            // a pair of lanes per path
+            const dim3 grid((unsigned)std::min<uint64_t>(((uint64_t)n_ext * 2 + kBlock - 1) / kBlock, ctx->ovf_threads / kBlock));
             DFrame f_frame = F;
             int f_k0 = k0, f_nk = nk;
             uint32_t f_n = n_ext;
-            void *fargs[] = {&a_scene, &f_frame, &f_k0, &f_nk, &P, &queue_in, &f_n, &a_ctr};
+            HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue.p, 0, kQueueBytes, s));
+            void *fargs[] = {&a_scene, &f_frame, &f_k0, &f_nk, &P, &queue_in, &f_n, &a_ctr, &a_queue};
             HIP_TRY(ctx, hipLaunchKernel(ff, grid, dim3(kBlock), fargs, lds, s));
             ctx->prog_round_done.store(items);
             break;
