@@ -39,6 +39,17 @@ struct TNode {
 };
 static_assert(sizeof(TNode) == 128, "one TNode per 128-byte line");
 
+// Hierarchy over the padded world-space boxes of the object nodes (the reference computes such boxes, src/scene.h:434-444,
+// and never looks at them: its rays are tested against every object, src/main.cpp:16-89).  Depth-first order with a skip
+// link: a walk goes to the next record when a box is reached and to `skip` when it is not - no stack, and with a
+// wave-uniform cursor every record arrives through the scalar cache.
+struct TlasNode {
+    float box[6];   // min xyz, max xyz
+    int32_t object; // scene node of a leaf, -1 for an inner record
+    int32_t skip;   // record to go on with when the box is not reached (= the end of this record's subtree)
+};
+static_assert(sizeof(TlasNode) == 32, "two records per 64-byte line");
+
 // One triangle mesh.  The BVH nodes and triangle records of all meshes of a scene live in two pools (one
 // allocation each); node ids and triangle offsets inside the BVH data words are pool indices.
 //   bvh  : the node pool.  32-byte nodes, two float4 each: (min.x, max.x, min.y, max.y) (min.z, max.z, data, 0);
@@ -72,6 +83,8 @@ struct DTexture {
 struct DScene {
     const DNode *nodes;
     const TNode *tnodes;       // the same nodes, compact (ray-list kernel)
+    const TlasNode *tlas;      // hierarchy over the object nodes' world boxes; null for scenes of a few objects
+    int32_t n_tlas;
     const float4 *bvh_pool;    // BVH nodes of all meshes
     const float4 *tri_pool;    // triangle records of all meshes
     // Four-wide form of the same BVHs: a record is one 128-byte line holding up to four nodes in the 32-byte layout

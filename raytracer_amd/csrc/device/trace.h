@@ -415,7 +415,37 @@ RT_DEV bool trace_closest(const DScene &S, Ray ray, LaneStack st, Hit &h, Tally<
     RayLevels<LEVELS> lv;
     lv.init(ray);
     const V3 winv = CULL ? cull_inverse(ray.d) : ray.d;
-    const int n = S.n_nodes;
+    const int n = (CULL && S.n_tlas > 0) ? 0 : S.n_nodes; // scenes of many objects: the hierarchy over their boxes, below
+    if (CULL && S.n_tlas > 0) {
+        // The wave walks the hierarchy together: a record is entered if any lane's ray reaches its box before that
+        // lane's closest hit so far.  Objects come up in the hierarchy's order, not the list's, so of two hits at
+        // exactly the same distance the one that is first in the list is kept explicitly (the reference keeps the first
+        // it meets, and it meets them in list order).
+        const Ray r0 = to_node(S.nodes[0], ray); // the root node's space
+        int cursor = 0;
+        while (cursor < S.n_tlas) {
+            const TlasNode &tn = S.tlas[__builtin_amdgcn_readfirstlane(cursor)];
+            const bool reach = reaches_box(tn.box, ray.p, winv, h.z);
+            if (!__any(reach)) { cursor = tn.skip; continue; }
+            ++cursor;
+            const int i = tn.object;
+            if (i < 0 || !reach) continue;
+            const DNode &nd = S.nodes[i];
+            Ray lr = r0;
+            for (int k = 1; k <= nd.depth; ++k) lr = to_node(S.nodes[nd.chain[k]], lr);
+            const int prim = nd.prim;
+            float t = 0; int front = 1; bool ok = false;
+            uint32_t face = 0; float u = 0, v = 0;
+            if (prim == RT_PRIM_SPHERE) ok = sphere_t(lr, t, front);
+            else if (prim == RT_PRIM_PLANE) ok = plane_t(lr, t, front);
+            else {
+                float det = 0;
+                ok = mesh_closest<COUNT>(S.meshes[nd.mesh], lr, st, t, face, u, v, det, tl);
+                front = det > 0.0f;
+            }
+            if (ok && (t < h.z || (t == h.z && i < h.node))) { h.z = t; h.node = i; h.front = front; h.face = face; h.u = u; h.v = v; }
+        }
+    }
     for (int i = 0; i < n; ++i) {
         const DNode &nd = S.nodes[i];
         const int d = nd.depth;
@@ -531,8 +561,30 @@ RT_DEV bool trace_shadow(const DScene &S, Ray ray, float t_max, LaneStack st, Ta
     RayLevels<LEVELS> lv;
     lv.init(ray);
     const V3 winv = CULL ? cull_inverse(ray.d) : ray.d;
-    const int n = S.n_nodes;
+    const int n = (CULL && S.n_tlas > 0) ? 0 : S.n_nodes;
     bool occluded = false;
+    if (CULL && S.n_tlas > 0) { // as in trace_closest; a lane that has its occluder stays in the walk and votes "no"
+        const Ray r0 = to_node(S.nodes[0], ray);
+        int cursor = 0;
+        while (cursor < S.n_tlas) {
+            const TlasNode &tn = S.tlas[__builtin_amdgcn_readfirstlane(cursor)];
+            const bool reach = !occluded && reaches_box(tn.box, ray.p, winv, t_max);
+            if (!__any(reach)) { cursor = tn.skip; continue; }
+            ++cursor;
+            const int i = tn.object;
+            if (i < 0) continue;
+            if (reach) {
+                const DNode &nd = S.nodes[i];
+                Ray lr = r0;
+                for (int k = 1; k <= nd.depth; ++k) lr = to_node(S.nodes[nd.chain[k]], lr);
+                const int prim = nd.prim;
+                if (prim == RT_PRIM_SPHERE) occluded = sphere_shadow(lr, t_max);
+                else if (prim == RT_PRIM_PLANE) occluded = plane_shadow(lr, t_max);
+                else occluded = mesh_shadow<COUNT>(S.meshes[nd.mesh], lr, t_max, st, tl);
+            }
+            if (__all(occluded)) break;
+        }
+    }
     for (int i = 0; i < n; ++i) {
         const DNode &nd = S.nodes[i];
         const int d = nd.depth;

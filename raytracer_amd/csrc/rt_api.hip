@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <limits>
 #include <memory>
 #include <string>
@@ -65,7 +66,7 @@ struct rt_ctx {
     // scene
     bool have_scene = false, have_meshes = false;
     DScene scene{};
-    DeviceBuf d_nodes, d_tnodes, d_meshes, d_materials, d_lights, d_textures;
+    DeviceBuf d_nodes, d_tnodes, d_tlas, d_meshes, d_materials, d_lights, d_textures;
     std::vector<std::unique_ptr<DeviceBuf>> mesh_bufs;
     std::vector<int> host_node_material; // for validation
     // camera
@@ -83,6 +84,7 @@ struct rt_ctx {
     uint32_t finish_below = 0; // RT_FINISH_BELOW: paths left in a round at which the wavefront pipeline hands over to k_wf_finish (default: 512 per CU; measured 8 k / 32 k / 128 k / 512 k: 101.3 / 99.8 / 98.3 / 99.2 ms per 1080p frame, 20.3 / 19.3 / 17.9 / 19.1 ms on an eighth of it)
     int pipeline = -1; // RT_PIPELINE: 0 = lock-step path kernel (k_paths), 1 = wavefront; -1: chosen per scene (wavefront when it has meshes)
     size_t ovf_threads = 0;
+    int tlas_min_objects = 8; // RT_TLAS_MIN: object nodes from which a scene gets the hierarchy over their boxes (0 = never)
     int lds_levels_max = 13;
     int n_cu = 256;
     int ray_levels = 1; // hierarchy levels that have children
@@ -445,6 +447,7 @@ int rt_init(int device, rt_ctx **out)
         if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
     if (const char *e8 = getenv("RT_CHUNK_ITEMS")) ctx->chunk_items = std::max(0, atoi(e8)) / 64 * 64;
     if (const char *e7 = getenv("RT_ORDER")) ctx->order_pixels = atoi(e7) != 0 ? 1 : 0;
+    if (const char *e10 = getenv("RT_TLAS_MIN")) ctx->tlas_min_objects = std::max(0, atoi(e10));
     if (const char *e2 = getenv("RT_LDS_LEVELS")) ctx->lds_levels_max = std::max(1, std::min(64, atoi(e2))); // tuning knob
     if ((e = ctx->d_queue.reserve(kQueueBytes)) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipHostMalloc((void **)&ctx->host_words, 64, hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess) return bail("hipHostMalloc", e);
@@ -719,6 +722,52 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc)
         const double padding = 1e-3 * extent + 1e-4;
         for (int a = 0; a < 3; ++a) { d.wbox[a] = (float)(wlo[a] - padding); d.wbox[3 + a] = (float)(whi[a] + padding); }
     }
+    // ---- hierarchy over the object nodes' world boxes (TlasNode): median splits of the box centres, one object per leaf ----
+    std::vector<TlasNode> tlas;
+    {
+        std::vector<int> boxed, unboxed;
+        for (uint32_t i = 0; i < nn; ++i) {
+            if (nodes[i].prim == RT_PRIM_NONE) continue;
+            (nodes[i].wbox[0] == -FLT_MAX ? unboxed : boxed).push_back((int)i);
+        }
+        if (ctx->tlas_min_objects > 0 && (int)(boxed.size() + unboxed.size()) >= ctx->tlas_min_objects) {
+            for (int i : unboxed) { // objects without a finite box: leaves every ray reaches
+                TlasNode t{};
+                for (int a = 0; a < 3; ++a) { t.box[a] = -FLT_MAX; t.box[3 + a] = FLT_MAX; }
+                t.object = i; t.skip = (int32_t)tlas.size() + 1;
+                tlas.push_back(t);
+            }
+            std::function<void(int, int)> build = [&](int lo, int hi) {
+                const size_t me = tlas.size();
+                tlas.push_back(TlasNode{});
+                float b[6] = {FLT_MAX, FLT_MAX, FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX}, c[6] = {FLT_MAX, FLT_MAX, FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
+                for (int k = lo; k < hi; ++k) {
+                    const float *w = nodes[boxed[k]].wbox;
+                    for (int a = 0; a < 3; ++a) {
+                        b[a] = std::min(b[a], w[a]); b[3 + a] = std::max(b[3 + a], w[3 + a]);
+                        const float mid = 0.5f * w[a] + 0.5f * w[3 + a];
+                        c[a] = std::min(c[a], mid); c[3 + a] = std::max(c[3 + a], mid);
+                    }
+                }
+                memcpy(tlas[me].box, b, sizeof b);
+                if (hi - lo == 1) tlas[me].object = boxed[lo];
+                else {
+                    tlas[me].object = -1;
+                    int axis = 0;
+                    for (int a = 1; a < 3; ++a) if (c[3 + a] - c[a] > c[3 + axis] - c[axis]) axis = a;
+                    const int mid = (lo + hi) / 2;
+                    std::nth_element(boxed.begin() + lo, boxed.begin() + mid, boxed.begin() + hi, [&](int x, int y) {
+                        const float cx = nodes[x].wbox[axis] + nodes[x].wbox[3 + axis], cy = nodes[y].wbox[axis] + nodes[y].wbox[3 + axis];
+                        return cx < cy || (cx == cy && x < y);
+                    });
+                    build(lo, mid);
+                    build(mid, hi);
+                }
+                tlas[me].skip = (int32_t)tlas.size();
+            };
+            if (!boxed.empty()) build(0, (int)boxed.size());
+        }
+    }
     // ---- textures ----
     const auto tex_ok = [&](int32_t t) { return t >= 0 && (uint32_t)t <= sc->n_textures; };
     if (!tex_ok(sc->background_texture) || !tex_ok(sc->environment_texture)) return ctx->fail(RT_ERR_INVALID, "background / environment texture index out of range");
@@ -762,6 +811,10 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc)
     HIP_TRY(ctx, ctx->d_tnodes.reserve(sizeof(TNode) * nn));
     HIP_TRY(ctx, hipMemcpy(ctx->d_tnodes.p, tnodes.data(), sizeof(TNode) * nn, hipMemcpyHostToDevice));
     S.tnodes = ctx->d_tnodes.as<TNode>();
+    HIP_TRY(ctx, ctx->d_tlas.reserve(sizeof(TlasNode) * std::max<size_t>(1, tlas.size())));
+    if (!tlas.empty()) HIP_TRY(ctx, hipMemcpy(ctx->d_tlas.p, tlas.data(), sizeof(TlasNode) * tlas.size(), hipMemcpyHostToDevice));
+    S.tlas = tlas.empty() ? nullptr : ctx->d_tlas.as<TlasNode>();
+    S.n_tlas = (int32_t)tlas.size();
     S.bvh_pool = d_bvh_pool; S.tri_pool = d_tri_pool; S.bvh4_pool = d_bvh4_pool;
     S.top4_base = top4_base; S.top4_count = top4_count;
     S.cancel = (const uint32_t *)&ctx->host_words[0];

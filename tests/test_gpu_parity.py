@@ -591,3 +591,36 @@ def test_multi_material_object_vs_reference(ctx, tmp_path, monkeypatch):
     bad.n_materials -= 1
     with pytest.raises(lib.RtError):
         ctx.upload(bad)
+
+
+def test_object_hierarchy_changes_nothing(monkeypatch, tmp_path):
+    """The Whitted kernel's scene walk through the hierarchy over the objects' world boxes (scenes of eight objects and
+    more by default; RT_TLAS_MIN=1 here: every scene) against the walk over the flat node list (RT_TLAS_MIN=0): the
+    hierarchy only decides which objects a wave looks at, so every plane is the same bit for bit - on the sphere grid,
+    on nested transformations (objects met out of list order, local rays rebuilt through the ancestors), on the
+    reference's own scene and on a mesh."""
+    from raytracer_amd import scenes
+    from test_host_side import multi_material_scene
+    cases = [
+        (lib.HostScene.from_string(scenes.spheres_scene_xml(seed=5, grid=6, width=160, height=90)), 0, 4),
+        (lib.HostScene.from_string(scenes.spheres_scene_xml(seed=7, grid=8, width=128, height=72)), 3, 2),
+        (lib.HostScene.from_string(scenes.nested_scene_xml(width=128, height=72)), 3, 2),
+        (lib.HostScene.from_string(scenes.cornell_scene_xml(128, 72)), 5, 2),
+        (multi_material_scene(O.load_golden("whitted_multimtl_96x54_b5"), tmp_path), 2, 2),
+    ]
+    frames = {}
+    for tlas_min in ("0", "1"):
+        monkeypatch.setenv("RT_TLAS_MIN", tlas_min)
+        c = lib.Context(0)
+        try:
+            for k, (hs, bounces, spp) in enumerate(cases):
+                prm = abi.default_params(seed=11 + k, min_spp=spp, max_spp=spp, max_bounces=bounces, mode=abi.RT_MODE_WHITTED)
+                frames[tlas_min, k] = render_gpu(c, hs, prm, hs.camera.width, hs.camera.height)
+        finally:
+            c.close()
+    for k in range(len(cases)):
+        a, b = frames["0", k], frames["1", k]
+        assert np.array_equal(a.object_id, b.object_id) and np.array_equal(bits(a.z), bits(b.z)), f"scene {k}: ids / z"
+        assert np.array_equal(bits(a.linear), bits(b.linear)), f"scene {k}: radiance"
+        assert np.array_equal(a.rgb, b.rgb) and np.array_equal(a.sample_count, b.sample_count)
+        assert (a.object_id >= 0).mean() > 0.3
