@@ -85,6 +85,11 @@ typedef struct rt_mesh {
     const uint32_t *fn;                 /* normal indices    [nf*3] */
     const uint32_t *ft;                 /* tex-coord indices [nf*3] */
     uint32_t nf;
+    /* The reference's BVH (cyBVH::Build, host side).  bvh_nodes == NULL: the library builds a BVH of its own on the GPU
+     * at rt_scene_upload (Morton order + one thread per node) - for every mesh of the scene if any mesh comes without
+     * one, or when RT_GPU_BVH=1 is set.  Depths and object ids of closest hits do not depend on which BVH is walked
+     * (same triangles, same triangle test); which of two triangles hit at exactly the same distance is reported, and
+     * the box / triangle test counters, do. */
     const rt_bvh_node *bvh_nodes; uint32_t n_bvh_nodes; /* including the unused node 0 */
     const uint32_t *bvh_elements;       /* face ids referenced by the leaves [nf] */
     uint32_t bvh_depth;                 /* depth of the deepest leaf, root = 0 */
@@ -236,6 +241,7 @@ typedef struct rt_counters {
     uint32_t trace_launches; /* how many such launches */
     uint32_t trace_pipeline; /* 0 = lock-step kernel (one launch per sampling round), 1 = wavefront pipeline (one k_rays launch per bounce) */
     uint64_t phase_cycles[16]; /* diagnostic builds only (RT_PROFILE_PHASES): per kernel phase wave clocks [0..3], executions [4..7], active lanes [8..11] */
+    double bvh_build_ms;    /* GPU time the last rt_scene_upload spent building BVHs (0: the scene brought them) */
 } rt_counters;
 
 /* ---- context ---- */
@@ -380,6 +386,10 @@ void rt_scene_host_free(rt_scene_host *s);
 int rt_scene_host_set_mesh(rt_scene_host *s, const char *node_name, const float *v, const float *vt,
                            uint32_t nv, const uint32_t *f, uint32_t nf, char *err, size_t err_len);
 
+/* on != 0: the scene's meshes go to rt_scene_upload without a BVH (the BVHs built so far are dropped, later
+ * rt_scene_host_set_mesh calls build none), so the library builds its own on the GPU; 0: back to the reference's
+ * BVH, built on the host. */
+int rt_scene_host_set_gpu_bvh(rt_scene_host *s, int on);
 /* rt_scene_desc.face_materials of a loaded scene: 0 (as loaded) shades every face of an OBJ object that brings its own
  * materials with the first of them, as the reference does; 1 shades a face with the material its `usemtl` group names. */
 int rt_scene_host_set_face_materials(rt_scene_host *s, int on);

@@ -1,0 +1,259 @@
+// A BVH built on the GPU, for scenes that arrive without one (rt_mesh::bvh_nodes == NULL) or ask for it (RT_GPU_BVH=1).
+//
+// The reference builds its BVH on the host, top down, splitting at the midpoint of the widest axis
+// (src/cyCore/cyBVH.h:122-142,242-328): seconds for ten million triangles.  Here the triangles are ordered along a
+// Morton curve (63-bit codes of the box centres, radix sort), the hierarchy over the sorted codes is built with one
+// thread per node (Karras, "Maximizing Parallelism in the Construction of BVHs, Octrees, and k-d Trees", 2012), boxes
+// are fitted bottom up, subtrees of at most four triangles become leaves, and the result is written in the two
+// layouts the kernels walk: the binary pool (32-byte nodes, children adjacent, DMesh::bvh) and the four-wide records
+// (DScene::bvh4_pool).  It is a different tree from the reference's: the same triangles are tested with the same
+// arithmetic, so the closest hit's distance and object are the same, but of two triangles hit at exactly the same
+// distance another one may be reported, and the box / triangle test counts are not the reference's.
+#pragma once
+#include "kernels.h"
+
+namespace rtd {
+
+constexpr uint32_t kLbvhLeaf = 0x80000000u; // child word: a sorted triangle position, not an internal node
+constexpr uint32_t kLbvhMaxLeafTris = 4;
+
+struct LbvhArrays {
+    const float *v;          // positions, 3 floats each
+    const uint32_t *f;       // 3 position indices per face
+    uint32_t n;              // faces
+    unsigned long long *keys; // Morton codes, sorted
+    uint32_t *order;         // face of sorted position k
+    uint2 *child;            // [n - 1] children of internal node i (kLbvhLeaf: sorted position)
+    uint32_t *parent;        // [n - 1] parent of internal node i | side << 31 (root: 0xFFFFFFFF)
+    uint32_t *leaf_parent;   // [n]     likewise for sorted position k
+    uint2 *range;            // [n - 1] first and last sorted position under internal node i
+    float *ibox, *lbox;      // [n - 1][6], [n][6]: min xyz, max xyz
+    uint32_t *arrived;       // [n - 1] children that have reported their boxes
+    uint32_t *inner;         // [n - 1] 1: more than kLbvhMaxLeafTris triangles below (stays an inner node); then its rank among those
+    uint32_t *depth;         // [n - 1] levels above a kept inner node
+    uint32_t *record;        // [n - 1] 1: gets a four-wide record (kept inner node at even depth); then its rank among those
+    uint32_t *max_depth;     // [1]
+};
+
+RT_DEV unsigned long long spread21(uint32_t x)
+{
+    unsigned long long v = x & 0x1FFFFFu;
+    v = (v | (v << 32)) & 0x1F00000000FFFFull;
+    v = (v | (v << 16)) & 0x1F0000FF0000FFull;
+    v = (v | (v << 8)) & 0x100F00F00F00F00Full;
+    v = (v | (v << 4)) & 0x10C30C30C30C30C3ull;
+    v = (v | (v << 2)) & 0x1249249249249249ull;
+    return v;
+}
+
+RT_DEV void tri_box(const float *v, const uint32_t *f, uint32_t face, float *b)
+{
+    const float *a = v + (size_t)f[face * 3] * 3, *c = v + (size_t)f[face * 3 + 1] * 3, *d = v + (size_t)f[face * 3 + 2] * 3;
+    for (int k = 0; k < 3; ++k) {
+        b[k] = fminf(a[k], fminf(c[k], d[k]));
+        b[3 + k] = fmaxf(a[k], fmaxf(c[k], d[k]));
+    }
+}
+
+// Morton code of every face's box centre inside the mesh's bounds
+__global__ __launch_bounds__(kBlock) void k_lbvh_keys(LbvhArrays A, float lo_x, float lo_y, float lo_z, float sx, float sy, float sz)
+{
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < A.n; i += gridDim.x * kBlock) {
+        float b[6];
+        tri_box(A.v, A.f, i, b);
+        const float cx = (0.5f * (b[0] + b[3]) - lo_x) * sx, cy = (0.5f * (b[1] + b[4]) - lo_y) * sy, cz = (0.5f * (b[2] + b[5]) - lo_z) * sz;
+        const auto cell = [](float c) { return (uint32_t)fminf(fmaxf(c, 0.0f), 2097151.0f); };
+        A.keys[i] = (spread21(cell(cx)) << 2) | (spread21(cell(cy)) << 1) | spread21(cell(cz));
+        A.order[i] = i;
+    }
+}
+
+// common leading bits of the codes at sorted positions i and j (equal codes: of the positions themselves), -1 outside
+RT_DEV int lbvh_delta(const unsigned long long *keys, int n, int i, int j)
+{
+    if (j < 0 || j >= n) return -1;
+    const unsigned long long a = keys[i], b = keys[j];
+    if (a != b) return __clzll((long long)(a ^ b));
+    return 64 + __clz(i ^ j);
+}
+
+// one thread per internal node: its range of sorted positions, its split, its children (Karras 2012, section 4)
+__global__ __launch_bounds__(kBlock) void k_lbvh_hierarchy(LbvhArrays A)
+{
+    const int n = (int)A.n;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n - 1; i += gridDim.x * kBlock) {
+        const int d = lbvh_delta(A.keys, n, i, i + 1) - lbvh_delta(A.keys, n, i, i - 1) >= 0 ? 1 : -1;
+        const int dmin = lbvh_delta(A.keys, n, i, i - d);
+        int lmax = 2;
+        while (lbvh_delta(A.keys, n, i, i + lmax * d) > dmin) lmax *= 2;
+        int l = 0;
+        for (int t = lmax / 2; t >= 1; t /= 2)
+            if (lbvh_delta(A.keys, n, i, i + (l + t) * d) > dmin) l += t;
+        const int j = i + l * d;
+        const int dnode = lbvh_delta(A.keys, n, i, j);
+        int s = 0;
+        for (int t = (l + 1) / 2;; t = (t + 1) / 2) {
+            if (lbvh_delta(A.keys, n, i, i + (s + t) * d) > dnode) s += t;
+            if (t == 1) break;
+        }
+        const int gamma = i + s * d + (d < 0 ? -1 : 0);
+        const int first = d > 0 ? i : j, last = d > 0 ? j : i;
+        const uint32_t left = first == gamma ? (uint32_t)gamma | kLbvhLeaf : (uint32_t)gamma;
+        const uint32_t right = last == gamma + 1 ? (uint32_t)(gamma + 1) | kLbvhLeaf : (uint32_t)(gamma + 1);
+        A.child[i] = make_uint2(left, right);
+        A.range[i] = make_uint2((uint32_t)first, (uint32_t)last);
+        if (left & kLbvhLeaf) A.leaf_parent[gamma] = (uint32_t)i; else A.parent[gamma] = (uint32_t)i;
+        if (right & kLbvhLeaf) A.leaf_parent[gamma + 1] = (uint32_t)i | 0x80000000u; else A.parent[gamma + 1] = (uint32_t)i | 0x80000000u;
+        if (i == 0) A.parent[0] = 0xFFFFFFFFu;
+        A.arrived[i] = 0;
+    }
+}
+
+// one thread per sorted position: the triangle's box, then up the tree; the second child to arrive at a node fits its box
+__global__ __launch_bounds__(kBlock) void k_lbvh_fit(LbvhArrays A)
+{
+    for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < A.n; k += gridDim.x * kBlock) {
+        float b[6];
+        tri_box(A.v, A.f, A.order[k], b);
+        for (int a = 0; a < 6; ++a) A.lbox[(size_t)k * 6 + a] = b[a];
+        if (A.n == 1) continue;
+        uint32_t p = A.leaf_parent[k] & 0x7FFFFFFFu;
+        for (;;) {
+            __threadfence(); // this child's box before the ticket
+            if (atomicAdd(&A.arrived[p], 1u) == 0) break; // the sibling will come by later
+            __threadfence();
+            const uint2 c = A.child[p];
+            const volatile float *l = (c.x & kLbvhLeaf) ? A.lbox + (size_t)(c.x & 0x7FFFFFFFu) * 6 : A.ibox + (size_t)c.x * 6;
+            const volatile float *r = (c.y & kLbvhLeaf) ? A.lbox + (size_t)(c.y & 0x7FFFFFFFu) * 6 : A.ibox + (size_t)c.y * 6;
+            for (int a = 0; a < 3; ++a) {
+                A.ibox[(size_t)p * 6 + a] = fminf(l[a], r[a]);
+                A.ibox[(size_t)p * 6 + 3 + a] = fmaxf(l[3 + a], r[3 + a]);
+            }
+            const uint32_t up = A.parent[p];
+            if (up == 0xFFFFFFFFu) break;
+            p = up & 0x7FFFFFFFu;
+        }
+    }
+}
+
+// which internal nodes stay inner nodes (more than four triangles below)
+__global__ __launch_bounds__(kBlock) void k_lbvh_mark_inner(LbvhArrays A)
+{
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i + 1 < A.n; i += gridDim.x * kBlock) {
+        const uint2 r = A.range[i];
+        A.inner[i] = r.y - r.x + 1 > kLbvhMaxLeafTris ? 1u : 0u;
+    }
+}
+
+// depth of every kept inner node (its ancestors are kept inner nodes too), which of them get a four-wide record
+__global__ __launch_bounds__(kBlock) void k_lbvh_depth(LbvhArrays A, const uint32_t *__restrict__ inner_flag)
+{
+    uint32_t deepest = 0;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i + 1 < A.n; i += gridDim.x * kBlock) {
+        uint32_t d = 0;
+        if (inner_flag[i]) {
+            for (uint32_t p = A.parent[i]; p != 0xFFFFFFFFu; p = A.parent[p & 0x7FFFFFFFu]) ++d;
+            deepest = d + 1 > deepest ? d + 1 : deepest; // its children are one level further down
+        }
+        A.depth[i] = d;
+        A.record[i] = inner_flag[i] && (d & 1u) == 0 ? 1u : 0u;
+    }
+    if (deepest) atomicMax(A.max_depth, deepest);
+}
+
+struct LbvhOut {
+    float4 *nodes;   // binary pool of this mesh: entry 0 is pool id `node_base`
+    float4 *recs;    // four-wide records of this mesh: entry 0 is record `rec_base`
+    float4 *tris;    // triangle records of this mesh: entry 0 is pool slot `tri_base`
+    uint32_t node_base, rec_base, tri_base;
+};
+
+// data word and box of a child of a kept inner node, in pool numbering: a leaf (at most four consecutive sorted
+// triangles) or another kept inner node (the pair of its own children)
+RT_DEV uint32_t lbvh_child_word(const LbvhArrays &A, const uint32_t *inner_rank, const uint32_t *inner_flag, uint32_t c, const LbvhOut &O,
+                                const float *&box, bool &is_inner)
+{
+    if (c & kLbvhLeaf) {
+        const uint32_t k = c & 0x7FFFFFFFu;
+        box = A.lbox + (size_t)k * 6; is_inner = false;
+        return 0x80000000u | (O.tri_base + k);
+    }
+    box = A.ibox + (size_t)c * 6;
+    if (!inner_flag[c]) {
+        const uint2 r = A.range[c];
+        is_inner = false;
+        return 0x80000000u | ((r.y - r.x) << 28) | (O.tri_base + r.x);
+    }
+    is_inner = true;
+    return O.node_base + 2u + 2u * inner_rank[c];
+}
+
+RT_DEV void lbvh_store_node(float4 *dst, const float *b, uint32_t word)
+{
+    dst[0] = make_float4(b[0], b[3], b[1], b[4]);
+    dst[1] = make_float4(b[2], b[5], __uint_as_float(word), 0.0f);
+}
+
+// the binary pool: a kept inner node writes its two children (adjacent, the pair at an even pool id), the root itself too
+__global__ __launch_bounds__(kBlock) void k_lbvh_emit_binary(LbvhArrays A, const uint32_t *__restrict__ inner_flag,
+                                                             const uint32_t *__restrict__ inner_rank, LbvhOut O)
+{
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i + 1 < A.n; i += gridDim.x * kBlock) {
+        if (!inner_flag[i]) continue;
+        const uint32_t pair = 2u + 2u * inner_rank[i]; // relative to node_base
+        if (i == 0) lbvh_store_node(O.nodes + 2, A.ibox, O.node_base + pair); // the root: pool id node_base + 1
+        const uint2 c = A.child[i];
+        const float *box; bool inner;
+        uint32_t w = lbvh_child_word(A, inner_rank, inner_flag, c.x, O, box, inner);
+        lbvh_store_node(O.nodes + (size_t)pair * 2, box, w);
+        w = lbvh_child_word(A, inner_rank, inner_flag, c.y, O, box, inner);
+        lbvh_store_node(O.nodes + (size_t)(pair + 1) * 2, box, w);
+    }
+}
+
+// the four-wide records: a kept inner node at even depth writes the boxes of its grandchildren (a child that is a
+// leaf stands for itself); an inner grandchild is named by its own record
+__global__ __launch_bounds__(kBlock) void k_lbvh_emit_wide(LbvhArrays A, const uint32_t *__restrict__ inner_flag, const uint32_t *__restrict__ inner_rank,
+                                                           const uint32_t *__restrict__ record_flag, const uint32_t *__restrict__ record_rank, LbvhOut O)
+{
+    const float inf = __builtin_inff();
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i + 1 < A.n; i += gridDim.x * kBlock) {
+        if (!record_flag[i]) continue;
+        float4 *rec = O.recs + (size_t)record_rank[i] * 8;
+        uint32_t slot = 0;
+        const uint2 c = A.child[i];
+        for (int side = 0; side < 2; ++side) {
+            const uint32_t ch = side ? c.y : c.x;
+            const float *box; bool inner;
+            const uint32_t w = lbvh_child_word(A, inner_rank, inner_flag, ch, O, box, inner);
+            if (!inner) { lbvh_store_node(rec + slot * 2, box, w); ++slot; continue; }
+            const uint2 g = A.child[ch];
+            for (int gs = 0; gs < 2; ++gs) {
+                const uint32_t gc = gs ? g.y : g.x;
+                const float *gbox; bool ginner;
+                uint32_t gw = lbvh_child_word(A, inner_rank, inner_flag, gc, O, gbox, ginner);
+                if (ginner) gw = O.rec_base + record_rank[gc]; // a kept inner node two levels down has a record of its own
+                lbvh_store_node(rec + slot * 2, gbox, gw);
+                ++slot;
+            }
+        }
+        for (; slot < 4; ++slot) { // boxes no ray enters
+            rec[slot * 2] = make_float4(inf, inf, inf, inf);
+            rec[slot * 2 + 1] = make_float4(inf, inf, __uint_as_float(0x7FFFFFFFu), 0.0f);
+        }
+    }
+}
+
+// triangle records in sorted order (the leaves' order): three positions and the face id
+__global__ __launch_bounds__(kBlock) void k_lbvh_emit_tris(LbvhArrays A, LbvhOut O)
+{
+    for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < A.n; k += gridDim.x * kBlock) {
+        const uint32_t face = A.order[k];
+        const float *a = A.v + (size_t)A.f[face * 3] * 3, *b = A.v + (size_t)A.f[face * 3 + 1] * 3, *c = A.v + (size_t)A.f[face * 3 + 2] * 3;
+        O.tris[(size_t)k * 3] = make_float4(a[0], a[1], a[2], b[0]);
+        O.tris[(size_t)k * 3 + 1] = make_float4(b[1], b[2], c[0], c[1]);
+        O.tris[(size_t)k * 3 + 2] = make_float4(c[2], __uint_as_float(face), 0.0f, 0.0f);
+    }
+}
+
+} // namespace rtd

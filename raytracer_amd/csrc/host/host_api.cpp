@@ -77,9 +77,26 @@ int rt_scene_host_set_mesh(rt_scene_host *s, const char *node_name, const float 
         m.ft = m.f;
         m.mtls.clear(); m.face_mtl.clear(); // an in-memory mesh brings no materials
         rt::compute_normals(m);
-        rt::build_bvh(m.v.data(), m.f.data(), nf, 4, m.bvh, m.elements, m.depth);
+        if (s->gpu_bvh) { m.bvh.clear(); m.elements.clear(); m.depth = 0; }
+        else rt::build_bvh(m.v.data(), m.f.data(), nf, 4, m.bvh, m.elements, m.depth);
     } catch (const std::exception &ex) {
         set_err(err, err_len, ex.what());
+        return RT_ERR_INVALID;
+    }
+    s->refresh_desc();
+    return RT_OK;
+}
+
+int rt_scene_host_set_gpu_bvh(rt_scene_host *s, int on)
+{
+    if (!s) return RT_ERR_INVALID;
+    s->gpu_bvh = on != 0;
+    try {
+        for (auto &m : s->meshes) {
+            if (s->gpu_bvh) { m->bvh.clear(); m->elements.clear(); m->depth = 0; }
+            else if (m->bvh.empty() && m->nf() > 0) rt::build_bvh(m->v.data(), m->f.data(), m->nf(), 4, m->bvh, m->elements, m->depth);
+        }
+    } catch (const std::exception &) {
         return RT_ERR_INVALID;
     }
     s->refresh_desc();

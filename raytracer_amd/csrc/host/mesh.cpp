@@ -19,8 +19,8 @@ rt_mesh HostMesh::desc() const
     d.vn = vn.data(); d.nvn = (uint32_t)(vn.size() / 3);
     d.vt = vt.data(); d.nvt = (uint32_t)(vt.size() / 3);
     d.f = f.data(); d.fn = fn.data(); d.ft = ft.data(); d.nf = nf();
-    d.bvh_nodes = bvh.data(); d.n_bvh_nodes = (uint32_t)bvh.size();
-    d.bvh_elements = elements.data(); d.bvh_depth = depth;
+    d.bvh_nodes = bvh.empty() ? nullptr : bvh.data(); d.n_bvh_nodes = (uint32_t)bvh.size();
+    d.bvh_elements = elements.empty() ? nullptr : elements.data(); d.bvh_depth = depth;
     if (!mtls.empty() && face_mtl.size() == nf()) { d.face_material = face_mtl.data(); d.n_sub_materials = (uint32_t)mtls.size(); }
     return d;
 }

@@ -59,6 +59,7 @@ struct rt_scene_host {
     rt_scene_desc desc{};
     rt_camera camera{};
     std::vector<std::string> warnings;
+    bool gpu_bvh = false; // meshes are described without a BVH: rt_scene_upload builds its own
 
     void refresh_desc();
 };

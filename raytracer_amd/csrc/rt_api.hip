@@ -4,6 +4,7 @@
 #include <hipcub/hipcub.hpp>
 #include "device/whitted.h"
 #include "device/kdbuild.h"
+#include "device/lbvh.h"
 #include "rt_mi355x.h"
 
 #include <algorithm>
@@ -84,6 +85,8 @@ struct rt_ctx {
     uint32_t finish_below = 0; // RT_FINISH_BELOW: paths left in a round at which the wavefront pipeline hands over to k_wf_finish (default: 512 per CU; measured 8 k / 32 k / 128 k / 512 k: 101.3 / 99.8 / 98.3 / 99.2 ms per 1080p frame, 20.3 / 19.3 / 17.9 / 19.1 ms on an eighth of it)
     int pipeline = -1; // RT_PIPELINE: 0 = lock-step path kernel (k_paths), 1 = wavefront; -1: chosen per scene (wavefront when it has meshes)
     size_t ovf_threads = 0;
+    bool gpu_bvh = false;     // RT_GPU_BVH=1: build every mesh's BVH on the GPU even if the scene brings one
+    double bvh_build_ms = 0;  // GPU time of the last upload's BVH builds
     int tlas_min_objects = 8; // RT_TLAS_MIN: object nodes from which a scene gets the hierarchy over their boxes (0 = never)
     int lds_levels_max = 13;
     int n_cu = 256;
@@ -447,6 +450,7 @@ int rt_init(int device, rt_ctx **out)
         if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
     if (const char *e8 = getenv("RT_CHUNK_ITEMS")) ctx->chunk_items = std::max(0, atoi(e8)) / 64 * 64;
     if (const char *e7 = getenv("RT_ORDER")) ctx->order_pixels = atoi(e7) != 0 ? 1 : 0;
+    if (const char *e11 = getenv("RT_GPU_BVH")) ctx->gpu_bvh = atoi(e11) != 0;
     if (const char *e10 = getenv("RT_TLAS_MIN")) ctx->tlas_min_objects = std::max(0, atoi(e10));
     if (const char *e2 = getenv("RT_LDS_LEVELS")) ctx->lds_levels_max = std::max(1, std::min(64, atoi(e2))); // tuning knob
     if ((e = ctx->d_queue.reserve(kQueueBytes)) != hipSuccess) return bail("hipMalloc", e);
@@ -482,6 +486,113 @@ int rt_set_counting(rt_ctx *ctx, int on)
 {
     if (!ctx) return RT_ERR_INVALID;
     ctx->counting = on != 0;
+    return RT_OK;
+}
+
+// One mesh's BVH built on the GPU (device/lbvh.h), in pool numbering: binary nodes from pool id node_base (the root is
+// node_base + 1), four-wide records from rec_base, triangle records from tri_base.
+struct GpuBvh {
+    std::unique_ptr<DeviceBuf> nodes, recs, tris;
+    uint32_t n_nodes = 0, n_recs = 0; // pool entries (binary nodes incl. the unused first two; records)
+    uint32_t root_word = 0, root4 = 0, depth = 0;
+    float bounds[6] = {0, 0, 0, 0, 0, 0};
+    double ms = 0;
+};
+
+static int build_bvh_gpu(rt_ctx *ctx, const rt_mesh &m, uint32_t node_base, uint32_t rec_base, uint32_t tri_base, GpuBvh &out)
+{
+    hipStream_t s = ctx->stream;
+    const uint32_t n = m.nf;
+    out.nodes = std::make_unique<DeviceBuf>(); out.recs = std::make_unique<DeviceBuf>(); out.tris = std::make_unique<DeviceBuf>();
+    // bounds of the triangles = of the vertices the faces name
+    float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (size_t k = 0; k < (size_t)n * 3; ++k) {
+        const float *q = m.v + (size_t)m.f[k] * 3;
+        for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], q[a]); hi[a] = std::max(hi[a], q[a]); }
+    }
+    for (int a = 0; a < 3; ++a) { out.bounds[a] = lo[a]; out.bounds[3 + a] = hi[a]; }
+    DeviceBuf d_v, d_f, keys[2], order[2], child, parent, leaf_parent, range, ibox, lbox, arrived, inner, inner_rank, depth, record, record_rank, maxd, tmp;
+    HIP_TRY(ctx, d_v.reserve((size_t)m.nv * 12)); HIP_TRY(ctx, d_f.reserve((size_t)n * 12));
+    HIP_TRY(ctx, hipMemcpyAsync(d_v.p, m.v, (size_t)m.nv * 12, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(d_f.p, m.f, (size_t)n * 12, hipMemcpyHostToDevice, s));
+    const size_t ni = n > 1 ? n - 1 : 1;
+    for (auto &b : keys) HIP_TRY(ctx, b.reserve((size_t)n * 8));
+    for (auto &b : order) HIP_TRY(ctx, b.reserve((size_t)n * 4));
+    HIP_TRY(ctx, child.reserve(ni * 8)); HIP_TRY(ctx, parent.reserve(ni * 4)); HIP_TRY(ctx, leaf_parent.reserve((size_t)n * 4));
+    HIP_TRY(ctx, range.reserve(ni * 8)); HIP_TRY(ctx, ibox.reserve(ni * 24)); HIP_TRY(ctx, lbox.reserve((size_t)n * 24));
+    HIP_TRY(ctx, arrived.reserve(ni * 4)); HIP_TRY(ctx, inner.reserve(ni * 4)); HIP_TRY(ctx, inner_rank.reserve(ni * 4));
+    HIP_TRY(ctx, depth.reserve(ni * 4)); HIP_TRY(ctx, record.reserve(ni * 4)); HIP_TRY(ctx, record_rank.reserve(ni * 4));
+    HIP_TRY(ctx, maxd.reserve(4));
+    HIP_TRY(ctx, hipMemsetAsync(maxd.p, 0, 4, s));
+    HIP_TRY(ctx, hipEventRecord(ctx->evk0, s));
+    LbvhArrays A{};
+    A.v = d_v.as<float>(); A.f = d_f.as<uint32_t>(); A.n = n;
+    A.keys = keys[0].as<unsigned long long>(); A.order = order[0].as<uint32_t>();
+    A.child = child.as<uint2>(); A.parent = parent.as<uint32_t>(); A.leaf_parent = leaf_parent.as<uint32_t>(); A.range = range.as<uint2>();
+    A.ibox = ibox.as<float>(); A.lbox = lbox.as<float>(); A.arrived = arrived.as<uint32_t>(); A.inner = inner.as<uint32_t>();
+    A.depth = depth.as<uint32_t>(); A.record = record.as<uint32_t>(); A.max_depth = maxd.as<uint32_t>();
+    const dim3 grid((unsigned)std::min<size_t>(((size_t)n + kBlock - 1) / kBlock, (size_t)ctx->n_cu * 16)), block(kBlock);
+    const auto scale = [&](int a) { return hi[a] > lo[a] ? 2097151.0f / (hi[a] - lo[a]) : 0.0f; };
+    hipLaunchKernelGGL(k_lbvh_keys, grid, block, 0, s, A, lo[0], lo[1], lo[2], scale(0), scale(1), scale(2));
+    size_t tmp_bytes = 0;
+    HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys[0].as<unsigned long long>(), keys[1].as<unsigned long long>(),
+                                                    order[0].as<uint32_t>(), order[1].as<uint32_t>(), (int)n, 0, 63, s));
+    HIP_TRY(ctx, tmp.reserve(std::max<size_t>(1, tmp_bytes)));
+    HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, keys[0].as<unsigned long long>(), keys[1].as<unsigned long long>(),
+                                                    order[0].as<uint32_t>(), order[1].as<uint32_t>(), (int)n, 0, 63, s));
+    A.keys = keys[1].as<unsigned long long>(); A.order = order[1].as<uint32_t>();
+    LbvhOut O{};
+    O.node_base = node_base; O.rec_base = rec_base; O.tri_base = tri_base;
+    HIP_TRY(ctx, out.tris->reserve((size_t)n * 48));
+    O.tris = out.tris->as<float4>();
+    uint32_t T = 0, R = 0;
+    if (n > kLbvhMaxLeafTris) {
+        hipLaunchKernelGGL(k_lbvh_hierarchy, grid, block, 0, s, A);
+        hipLaunchKernelGGL(k_lbvh_fit, grid, block, 0, s, A);
+        hipLaunchKernelGGL(k_lbvh_mark_inner, grid, block, 0, s, A);
+        const auto scan = [&](DeviceBuf &flags, DeviceBuf &ranks, uint32_t &total) -> int {
+            size_t bytes = 0;
+            HIP_TRY(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, flags.as<uint32_t>(), ranks.as<uint32_t>(), (int)(n - 1), s));
+            HIP_TRY(ctx, tmp.reserve(std::max<size_t>(1, bytes)));
+            HIP_TRY(ctx, hipcub::DeviceScan::ExclusiveSum(tmp.p, bytes, flags.as<uint32_t>(), ranks.as<uint32_t>(), (int)(n - 1), s));
+            uint32_t last[2] = {0, 0};
+            HIP_TRY(ctx, hipMemcpyAsync(&last[0], flags.as<uint32_t>() + (n - 2), 4, hipMemcpyDeviceToHost, s));
+            HIP_TRY(ctx, hipMemcpyAsync(&last[1], ranks.as<uint32_t>() + (n - 2), 4, hipMemcpyDeviceToHost, s));
+            HIP_TRY(ctx, hipStreamSynchronize(s));
+            total = last[0] + last[1];
+            return RT_OK;
+        };
+        if (int rc = scan(inner, inner_rank, T)) return rc;
+        hipLaunchKernelGGL(k_lbvh_depth, grid, block, 0, s, A, inner.as<uint32_t>());
+        if (int rc = scan(record, record_rank, R)) return rc;
+        if ((uint64_t)node_base + 2 + 2ull * T >= (1ull << 31) || (uint64_t)rec_base + R >= (1ull << 31)) return ctx->fail(RT_ERR_UNSUPPORTED, "scene has too many BVH nodes");
+        out.n_nodes = 2 + 2 * T; out.n_recs = R;
+        HIP_TRY(ctx, out.nodes->reserve((size_t)out.n_nodes * 32)); HIP_TRY(ctx, out.recs->reserve(std::max<size_t>(1, (size_t)R * 128)));
+        HIP_TRY(ctx, hipMemsetAsync(out.nodes->p, 0, 64, s));
+        O.nodes = out.nodes->as<float4>(); O.recs = out.recs->as<float4>();
+        hipLaunchKernelGGL(k_lbvh_emit_binary, grid, block, 0, s, A, inner.as<uint32_t>(), inner_rank.as<uint32_t>(), O);
+        hipLaunchKernelGGL(k_lbvh_emit_wide, grid, block, 0, s, A, inner.as<uint32_t>(), inner_rank.as<uint32_t>(), record.as<uint32_t>(), record_rank.as<uint32_t>(), O);
+        out.root_word = node_base + 2; // the pair of the root's children: the root is the first kept inner node
+        out.root4 = rec_base;          // ... and the first record
+    } else { // a handful of triangles: the root is a leaf
+        out.n_nodes = 2; out.n_recs = 0;
+        HIP_TRY(ctx, out.nodes->reserve(64)); HIP_TRY(ctx, out.recs->reserve(1));
+        out.root_word = 0x80000000u | ((n - 1) << 28) | tri_base;
+        out.root4 = out.root_word;
+        const float4 root[4] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(lo[0], hi[0], lo[1], hi[1]),
+                                make_float4(lo[2], hi[2], __builtin_bit_cast(float, out.root_word), 0.0f)};
+        HIP_TRY(ctx, hipMemcpyAsync(out.nodes->p, root, sizeof root, hipMemcpyHostToDevice, s));
+    }
+    hipLaunchKernelGGL(k_lbvh_emit_tris, grid, block, 0, s, A, O);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->evk1, s));
+    uint32_t deepest = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&deepest, maxd.p, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    float ms = 0;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->evk0, ctx->evk1));
+    out.ms = ms;
+    out.depth = deepest;
     return RT_OK;
 }
 
@@ -552,17 +663,32 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc)
     };
     std::vector<uint32_t> node_base(sc->n_meshes), tri_base(sc->n_meshes);
     size_t pool_nodes = 2, pool_tris = 0; // pool node 0/1 unused: pairs of children start at even ids
+    // A scene whose meshes come without a BVH (or RT_GPU_BVH=1) gets them built here, on the GPU (device/lbvh.h)
+    bool gpu_bvh = ctx->gpu_bvh;
+    for (uint32_t mi = 0; mi < sc->n_meshes; ++mi) gpu_bvh = gpu_bvh || !sc->meshes[mi].bvh_nodes || !sc->meshes[mi].bvh_elements;
+    std::vector<GpuBvh> built(gpu_bvh ? sc->n_meshes : 0);
+    size_t pool_recs = 0;
+    double build_ms = 0;
     for (uint32_t mi = 0; mi < sc->n_meshes; ++mi) {
         const rt_mesh &m = sc->meshes[mi];
-        if (!m.v || !m.vn || !m.vt || !m.f || !m.fn || !m.ft || !m.bvh_nodes || !m.bvh_elements || m.nf == 0 || m.n_bvh_nodes < 2)
-            return ctx->fail(RT_ERR_INVALID, "mesh %u: missing arrays (positions, normals, tex coords, faces and BVH are all required)", mi);
+        if (!m.v || !m.vn || !m.vt || !m.f || !m.fn || !m.ft || m.nf == 0 || (!gpu_bvh && (!m.bvh_nodes || !m.bvh_elements || m.n_bvh_nodes < 2)))
+            return ctx->fail(RT_ERR_INVALID, "mesh %u: missing arrays (positions, normals, tex coords and faces are all required)", mi);
         node_base[mi] = (uint32_t)pool_nodes; tri_base[mi] = (uint32_t)pool_tris;
+        if (gpu_bvh) {
+            if (m.nf >= (1u << 28)) return ctx->fail(RT_ERR_UNSUPPORTED, "scene has more than 2^28 triangles");
+            for (size_t k = 0; k < (size_t)m.nf * 3; ++k)
+                if (m.f[k] >= m.nv) return ctx->fail(RT_ERR_INVALID, "mesh %u: face index out of range", mi);
+            if (int rc = build_bvh_gpu(ctx, m, node_base[mi], (uint32_t)pool_recs, tri_base[mi], built[mi])) return rc;
+            pool_nodes += built[mi].n_nodes;
+            pool_recs += built[mi].n_recs;
+            build_ms += built[mi].ms;
+        } else
         pool_nodes += ((size_t)m.n_bvh_nodes + 1) / 2 * 2;
         pool_tris += m.nf;
         if (pool_nodes >= ((size_t)1 << 31) || pool_tris >= ((size_t)1 << 28)) return ctx->fail(RT_ERR_UNSUPPORTED, "scene has more than 2^28 triangles");
     }
-    std::vector<float4> bvh(pool_nodes * 2, make_float4(0, 0, 0, 0));
-    std::vector<float4> tris(pool_tris * 3);
+    std::vector<float4> bvh(gpu_bvh ? 0 : pool_nodes * 2, make_float4(0, 0, 0, 0));
+    std::vector<float4> tris(gpu_bvh ? 0 : pool_tris * 3);
     std::vector<rt_bvh_node> roots(sc->n_meshes);
     std::vector<float4> bvh4; // records of eight float4
     std::vector<uint32_t> root4(sc->n_meshes, 0);
@@ -574,6 +700,13 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc)
         // BVH: walk it once - checks indices, finds the depth, proves it is a tree
         const uint32_t nb = node_base[mi], tb = tri_base[mi];
         uint32_t depth = 0;
+        if (gpu_bvh) {
+            const GpuBvh &g = built[mi];
+            depth = g.depth;
+            memcpy(roots[mi].bounds, g.bounds, sizeof g.bounds);
+            roots[mi].data = g.root_word;
+            root4[mi] = g.root4;
+        } else {
         size_t visited = 0;
         std::vector<std::pair<uint32_t, uint32_t>> stack{{1u, 0u}};
         while (!stack.empty()) {
@@ -653,9 +786,10 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc)
                 top4_count = (uint32_t)std::min<size_t>(n_rec, (size_t)kTop4Records);
             }
         }
+        } // host-built BVH
         max_mesh_depth = std::max(max_mesh_depth, (int)depth);
         DMesh &d = dmeshes[mi];
-        d.n_nodes = m.n_bvh_nodes; d.depth = depth; d.root = nb + 1;
+        d.n_nodes = gpu_bvh ? built[mi].n_nodes : m.n_bvh_nodes; d.depth = depth; d.root = nb + 1;
         HIP_TRY(ctx, upload(m.fn, (size_t)m.nf * 12, (const void **)&d.fn));
         HIP_TRY(ctx, upload(m.ft, (size_t)m.nf * 12, (const void **)&d.ft));
         HIP_TRY(ctx, upload(m.vn, (size_t)m.nvn * 12, (const void **)&d.vn));
@@ -669,12 +803,36 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc)
         }
     }
     const float4 *d_bvh_pool = nullptr, *d_tri_pool = nullptr, *d_bvh4_pool = nullptr;
-    if (sc->n_meshes) {
+    if (sc->n_meshes && gpu_bvh) { // the meshes' parts, each built in pool numbering, side by side in the three pools
+        auto pool = [&](size_t bytes, const void **dst) -> hipError_t {
+            auto b = std::make_unique<DeviceBuf>();
+            hipError_t e = b->reserve(std::max<size_t>(128, bytes));
+            *dst = b->p;
+            bufs.push_back(std::move(b));
+            return e;
+        };
+        HIP_TRY(ctx, pool(pool_nodes * 32, (const void **)&d_bvh_pool));
+        HIP_TRY(ctx, pool(pool_recs * 128, (const void **)&d_bvh4_pool));
+        HIP_TRY(ctx, pool(pool_tris * 48, (const void **)&d_tri_pool));
+        HIP_TRY(ctx, hipMemset((void *)d_bvh_pool, 0, 64));
+        size_t rec_at = 0;
+        for (uint32_t mi = 0; mi < sc->n_meshes; ++mi) {
+            GpuBvh &g = built[mi];
+            HIP_TRY(ctx, hipMemcpy((char *)d_bvh_pool + (size_t)node_base[mi] * 32, g.nodes->p, (size_t)g.n_nodes * 32, hipMemcpyDeviceToDevice));
+            if (g.n_recs) HIP_TRY(ctx, hipMemcpy((char *)d_bvh4_pool + rec_at * 128, g.recs->p, (size_t)g.n_recs * 128, hipMemcpyDeviceToDevice));
+            HIP_TRY(ctx, hipMemcpy((char *)d_tri_pool + (size_t)tri_base[mi] * 48, g.tris->p, (size_t)sc->meshes[mi].nf * 48, hipMemcpyDeviceToDevice));
+            rec_at += g.n_recs;
+            g.nodes.reset(); g.recs.reset(); g.tris.reset();
+        }
+        for (DMesh &d : dmeshes) { d.bvh = d_bvh_pool; d.tris = d_tri_pool; }
+        ctx->bvh_build_ms = build_ms;
+    } else if (sc->n_meshes) {
         if (bvh4.empty()) bvh4.resize(8, make_float4(0, 0, 0, 0));
         HIP_TRY(ctx, upload(bvh4.data(), bvh4.size() * sizeof(float4), (const void **)&d_bvh4_pool));
         HIP_TRY(ctx, upload(bvh.data(), bvh.size() * sizeof(float4), (const void **)&d_bvh_pool));
         HIP_TRY(ctx, upload(tris.data(), tris.size() * sizeof(float4), (const void **)&d_tri_pool));
         for (DMesh &d : dmeshes) { d.bvh = d_bvh_pool; d.tris = d_tri_pool; }
+        ctx->bvh_build_ms = 0;
     }
     // compact node records of the ray-list kernel
     std::vector<TNode> tnodes(nn);
@@ -700,7 +858,7 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc)
         double lo[3] = {-1, -1, -1}, hi[3] = {1, 1, 1}; // unit sphere; unit square in z = 0
         if (d.prim == RT_PRIM_PLANE) lo[2] = hi[2] = 0;
         else if (d.prim == RT_PRIM_MESH) {
-            const rt_bvh_node &root = sc->meshes[d.mesh].bvh_nodes[1];
+            const rt_bvh_node &root = roots[d.mesh];
             for (int a = 0; a < 3; ++a) { lo[a] = root.bounds[a]; hi[a] = root.bounds[3 + a]; }
         } else if (d.prim != RT_PRIM_SPHERE) continue;
         double wlo[3] = {1e300, 1e300, 1e300}, whi[3] = {-1e300, -1e300, -1e300};
@@ -863,6 +1021,7 @@ int rt_get_counters(rt_ctx *ctx, rt_counters *out)
 {
     if (!ctx || !out) return RT_ERR_INVALID;
     *out = ctx->counters;
+    out->bvh_build_ms = ctx->bvh_build_ms;
     return RT_OK;
 }
 

@@ -20,7 +20,7 @@ SYMBOLS = (
     "rt_abi_version", "rt_init", "rt_shutdown", "rt_last_error", "rt_scene_upload", "rt_camera_set", "rt_render",
     "rt_trace", "rt_trace_shadow", "rt_trace_brief", "rt_trace_brief_noalloc", "rt_trace_paths", "rt_get_counters", "rt_set_counting",
     "rt_scene_load_xml", "rt_scene_from_xml_string", "rt_scene_host_desc", "rt_scene_host_camera",
-    "rt_scene_host_free", "rt_scene_host_set_mesh", "rt_scene_host_set_face_materials", "rt_scene_host_warning", "rt_png_decode_rgb8",
+    "rt_scene_host_free", "rt_scene_host_set_mesh", "rt_scene_host_set_face_materials", "rt_scene_host_set_gpu_bvh", "rt_scene_host_warning", "rt_png_decode_rgb8",
     "rt_bvh_build", "rt_free",
     "rt_cancel", "rt_progress", "rt_frame_records", "rt_frame_pack", "rt_frame_unpack", "rt_photons_emit", "rt_photons_build", "rt_photons_fill", "rt_photons_download", "rt_photons_irradiance",
 )
@@ -81,6 +81,7 @@ def load():
     L.rt_scene_host_set_mesh.argtypes = [vp, C.c_char_p, abi.f32p, abi.f32p, C.c_uint32, abi.u32p, C.c_uint32,
                                          C.c_char_p, C.c_size_t]
     L.rt_scene_host_set_face_materials.argtypes = [vp, C.c_int]
+    L.rt_scene_host_set_gpu_bvh.argtypes = [vp, C.c_int]
     L.rt_scene_host_warning.argtypes = [vp, C.c_uint32]
     L.rt_scene_host_warning.restype = C.c_char_p
     L.rt_png_decode_rgb8.argtypes = [C.c_char_p, C.c_size_t, abi.i32p, abi.i32p, C.POINTER(abi.u8p), C.c_char_p, C.c_size_t]
@@ -139,6 +140,13 @@ class HostScene:
         """Shade the faces of an OBJ object that brings its own materials each with the one it names (the reference
         shades them all with the first: it never sets HitInfo::mtlID)."""
         load().rt_scene_host_set_face_materials(self._h, int(on))
+
+    def set_gpu_bvh(self, on):
+        """Describe the meshes without a BVH (rt_scene_upload then builds its own on the GPU) / with the reference's again."""
+        rc = load().rt_scene_host_set_gpu_bvh(self._h, int(on))
+        if rc:
+            raise RtError(rc, "rt_scene_host_set_gpu_bvh")
+        self.desc = load().rt_scene_host_desc(self._h).contents
 
     def warnings(self):
         out, n = [], 0

@@ -1,0 +1,146 @@
+"""The BVH the library builds on the GPU for meshes that come without one (Morton order, one thread per node), behind
+the gate the depth / id planes set: it is another tree than the reference's, but it holds the same triangles, tested
+with the same arithmetic - so closest-hit distances and object ids are the reference's bit for bit, and images agree to
+the tolerance of the other image tests.  Checked against fixtures made by the reference itself, at 1 024, 1 000 000 and
+10 000 000 triangles, through the query entry points, the lock-step kernels and the wavefront pipeline."""
+import numpy as np
+import pytest
+
+import oraclelib as O
+from raytracer_amd import abi, lib, scenes
+
+PSNR_MIN = 45.0
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def test_scene_without_bvh_is_described_without_one():
+    g = O.load_golden("scene_mesh")
+    mesh = scenes.heightfield(nx=int(g["mesh_nx"]), ny=int(g["mesh_ny"]))
+    hs = lib.HostScene.from_string(bytes(g["xml"]).decode())
+    hs.set_gpu_bvh(True)
+    hs.set_mesh("mesh_small.obj", mesh["v"], mesh["vt"], mesh["f"])
+    m = hs.desc.meshes[0]
+    assert m.nf == 1024 and not m.bvh_nodes and not m.bvh_elements and m.n_bvh_nodes == 0
+    hs.set_gpu_bvh(False)  # the reference's BVH again, as if it had never been dropped
+    from test_host_side import check_mesh
+    check_mesh(hs.desc.meshes[0], g)
+
+
+def mesh_scene(golden, name, nx, ny, gpu_bvh):
+    mesh = scenes.heightfield(nx, ny)
+    hs = lib.HostScene.from_string(bytes(golden["xml"]).decode())
+    hs.set_gpu_bvh(gpu_bvh)
+    hs.set_mesh(name, mesh["v"], mesh["vt"], mesh["f"])
+    return hs
+
+
+def check_rays(ctx, g):
+    hits = ctx.trace(g["kat_rays"])
+    ref_hit = g["kat_flags"][:, 0].astype(bool)
+    assert np.array_equal(hits["node"], g["kat_id"]), "hit node ids"
+    assert np.array_equal(bits(hits["z"]), bits(g["kat_hit"][:, 0])), "z"
+    on_obj = ref_hit & (g["kat_id"] >= 0)
+    assert np.array_equal(bits(hits["p"][on_obj]), bits(g["kat_hit"][on_obj, 1:4])), "hit point"
+    assert np.array_equal(ctx.trace_shadow(g["kat_rays"], g["kat_tmax"]), g["kat_flags"][:, 2]), "shadow rays"
+    brief = ctx.trace_brief(g["kat_rays"])
+    assert np.array_equal(brief["node"], g["kat_id"]) and np.array_equal(bits(brief["t"]), bits(g["kat_hit"][:, 0]))
+    assert np.array_equal(ctx.trace_brief(g["kat_rays"], g["kat_tmax"])["node"], g["kat_flags"][:, 2])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lds_levels", [None, "3"])
+def test_small_mesh_fixtures_with_gpu_bvh(monkeypatch, lds_levels):
+    if lds_levels:
+        monkeypatch.setenv("RT_LDS_LEVELS", lds_levels)  # the walk's stack overflows into global memory
+    g = O.load_golden("kat_trace_mesh")
+    hs = mesh_scene(O.load_golden("scene_mesh"), "mesh_small.obj", 32, 16, True)
+    ctx = lib.Context(0)
+    try:
+        ctx.upload(hs.desc)
+        assert ctx.counters().bvh_build_ms > 0
+        check_rays(ctx, g)
+        for name in ("image_mesh_96x54_s8", "whitted_mesh_96x54_b5"):
+            g = O.load_golden(name)
+            seed, mn, mx, w, h = [int(x) for x in g["params"][:5]]
+            kw = dict(seed=seed, min_spp=mn, max_spp=mx, delta_max=float(g["delta"]))
+            if name.startswith("whitted"):
+                kw.update(mode=abi.RT_MODE_WHITTED, max_bounces=int(g["params"][5]))
+            ctx.set_camera(hs.camera, w, h)
+            fr = ctx.render(abi.default_params(**kw))
+            assert np.array_equal(fr.object_id, g["object_id"]), name
+            assert np.array_equal(bits(fr.z), bits(g["z"])), name
+            assert O.psnr(fr.rgb, g["rgb"]) >= PSNR_MIN, name
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pipeline", ["wave", "mega"])
+def test_config_c_with_gpu_bvh(monkeypatch, pipeline):
+    """The 1M-triangle frame: the reference's rays and its band of the frame, through both forms of the path tracer."""
+    monkeypatch.setenv("RT_PIPELINE", pipeline)
+    g = O.load_golden("config_c_1m")
+    hs = mesh_scene(g, "mesh_1m.obj", int(g["mesh_nx"]), int(g["mesh_ny"]), True)
+    ctx = lib.Context(0)
+    try:
+        ctx.upload(hs.desc)
+        ms = ctx.counters().bvh_build_ms
+        assert 0 < ms < 200, f"BVH of 1M triangles built in {ms:.1f} ms"
+        check_rays(ctx, g)
+        seed, mn, mx, w, h, y0, y1 = [int(x) for x in g["params"]]
+        ctx.set_camera(hs.camera, w, h)
+        fr = ctx.render(abi.default_params(seed=seed, min_spp=mn, max_spp=mx, delta_max=float(g["delta"])))
+        assert np.array_equal(fr.object_id[y0:y1], g["object_id"]), "primary-hit ids"
+        assert np.array_equal(bits(fr.z[y0:y1]), bits(g["z"])), "z-buffer"
+        assert np.array_equal(fr.sample_count[y0:y1], g["sample_count"])
+        p = O.psnr(fr.rgb[y0:y1], g["rgb"])
+        assert p >= PSNR_MIN, f"PSNR {p:.2f} dB vs the reference's band"
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
+def test_config_e_rays_with_gpu_bvh():
+    """Ten million triangles: built in well under a second, the reference's 4096 aimed rays answered bit for bit."""
+    g = O.load_golden("config_e_10m")
+    hs = mesh_scene(g, "mesh_10m.obj", int(g["mesh_nx"]), int(g["mesh_ny"]), True)
+    ctx = lib.Context(0)
+    try:
+        ctx.upload(hs.desc)
+        ms = ctx.counters().bvh_build_ms
+        assert 0 < ms < 1000, f"BVH of 10M triangles built in {ms:.1f} ms"
+        check_rays(ctx, g)
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
+def test_objects_of_few_triangles_and_two_meshes(tmp_path):
+    """A mesh of two triangles (its root is a leaf) next to a larger one, both built on the GPU, against the walk
+    through the reference's BVHs: ids and depths equal.  (The quad is tilted: the reference's slab test never enters a
+    box of no thickness, so a mesh that lies in an axis plane is invisible to it.)"""
+    quad = "v -3 -3 0\nv 3 -3 0.5\nv 3 3 1\nv -3 3 0.5\nvt 0 0 0\nvt 1 0 0\nvt 1 1 0\nvt 0 1 0\nf 1/1 2/2 3/3\nf 1/1 3/3 4/4\n"
+    (tmp_path / "quad.obj").write_text(quad)
+    mesh = scenes.heightfield(24, 12, 6.0, 4.0)
+    scenes.write_obj(tmp_path / "hills.obj", mesh)
+    xml = scenes.mesh_scene_xml("hills.obj", 128, 72).replace(
+        '<object type="obj" name="hills.obj"', '<object type="obj" name="quad.obj" material="smooth"><translate z="7"/></object>\n    <object type="obj" name="hills.obj"', 1)
+    frames = []
+    for gpu in (False, True):
+        hs = lib.HostScene.from_string(xml, str(tmp_path))
+        assert hs.desc.n_meshes == 2
+        hs.set_gpu_bvh(gpu)
+        ctx = lib.Context(0)
+        try:
+            ctx.upload(hs.desc)
+            ctx.set_camera(hs.camera, 128, 72)
+            frames.append(ctx.render(abi.default_params(seed=3, min_spp=4, max_spp=4)))
+        finally:
+            ctx.close()
+    a, b = frames
+    assert {1, 2} <= set(np.unique(a.object_id))
+    assert np.array_equal(a.object_id, b.object_id) and np.array_equal(bits(a.z), bits(b.z))
+    assert O.psnr(a.rgb, b.rgb) >= PSNR_MIN
