@@ -172,7 +172,7 @@ struct WorkQueue {
 };
 
 #ifndef RT_PATHS_MIN_WAVES
-#define RT_PATHS_MIN_WAVES 6 // waves per SIMD the register allocator must leave room for
+#define RT_PATHS_MIN_WAVES 3 // waves per SIMD the register allocator must leave room for: 170 registers.  The kernel runs the scenes without meshes (a scene with one goes through the wavefront pipeline), where it is bound by its own arithmetic: at 6 waves (80 registers) it spills 220 values and the reference's scene takes 65 ms, at 4: 56 ms, at 3: 38 ms, at 2: 46 ms
 #endif
 
 template <bool COUNT, int LEVELS, bool TEXBG>
