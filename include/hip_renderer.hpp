@@ -124,6 +124,7 @@ class HipRenderer {
     mutable std::mutex gpu; // one call at a time on the context (rt_cancel and rt_progress excepted)
     rt_render_params params{};
     std::atomic<int> lastStatus{RT_OK};
+    bool gpuBvh = false, faceMaterials = false;
 
     bool Fail(const char *what, const char *msg) const
     {
@@ -169,10 +170,20 @@ public:
         if (host) rt_scene_host_free(host);
         host = h;
         sceneFile = sceneFilename;
+        rt_scene_host_set_face_materials(host, faceMaterials ? 1 : 0);
+        if (gpuBvh) rt_scene_host_set_gpu_bvh(host, 1);
         if ((lastStatus = rt_scene_upload(ctx, rt_scene_host_desc(host))) != RT_OK) return Fail("rt_scene_upload", rt_last_error(ctx));
         camera = *rt_scene_host_camera(host);
         return SetCamera();
     }
+    // Scenes loaded from here on go to the GPU without the reference's BVH: the library builds its own there (milliseconds
+    // instead of the seconds cyBVH::Build takes for millions of triangles; same depths and object ids, frames a few per
+    // cent slower).  Call before LoadScene.
+    void UseGpuBvh(bool on) { gpuBvh = on; }
+    // Objects that bring their own materials (the reference's MultiMtl): false (default) shades every face with the first
+    // member, as the reference does - its intersectors never set HitInfo::mtlID; true: each face with the member it names.
+    void UseFaceMaterials(bool on) { faceMaterials = on; }
+
     bool SetCamera()
     {
         if (!ctx) return false;
