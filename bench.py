@@ -5,7 +5,9 @@
 
 One step = one frame of the workload: every rank renders its tile shard
 (camera rays, BVH traversal, shading, resolve), the framebuffer is gathered
-(RCCL all_gather, N > 1) and rank 0 copies the finished frame to the host.
+(RCCL all_gather, N > 1) and rank 0 copies the finished frame to the host
+(the copy of frame i runs while frame i + 1 renders into a second set of
+planes; the timed region ends when the last copy has).
 A ray is one TraceRay or TraceShadowRay call equivalent of the reference
 (src/main.cpp:115-125); rays are counted by the kernels, not estimated.
 
@@ -228,23 +230,31 @@ def main():
                              max_bounces=bounces, photon_flags=pp.flags if pp else 0, gather_radius=3.0)
     if args.tile_size:
         prm.tile_size = args.tile_size
-    fb = FrameBuffers(w, h, dev)
+    # two sets of planes and host images, used in turn: the copy of a finished frame to the host (queued on torch's stream)
+    # runs while the library, on its own stream, renders the next frame into the other set
+    fbs = [FrameBuffers(w, h, dev), FrameBuffers(w, h, dev)]
+    fb = fbs[0]
     gather = FrameGather(w, h, prm.tile_size, rank, world, dev, ctx=ctx, exchange=grouped)
     filler = PhotonFill(ctx, rank, world, dev) if pp else None
-    host_rgb = torch.empty((w * h, 3), dtype=torch.uint8).pin_memory()
+    host_rgbs = [torch.empty((w * h, 3), dtype=torch.uint8).pin_memory() for _ in fbs]
+    copied = [torch.cuda.Event() for _ in fbs]
     photon_stats = {}
+    frames = [0]
 
     def step():
-        # the library renders on its own stream: what the previous step queued on torch's stream (unpacking the
-        # gathered pixels, the copy to the host) must be through with the planes before they are written again
-        torch.cuda.current_stream().synchronize()
+        k = frames[0] % 2
+        frames[0] += 1
+        f = fbs[k]
+        copied[k].synchronize()  # the copy out of this set of planes, two frames ago, before they are written again
         if filler:  # the maps are part of the frame: emitted by all ranks, gathered, balanced on every rank
+            torch.cuda.current_stream().synchronize()
             photon_stats.update(filler(pp))
-        ctx.render_device(prm, rgb=fb.rgb.data_ptr(), z=fb.z.data_ptr(), sample_count=fb.sample_count.data_ptr(),
-                          object_id=fb.object_id.data_ptr())
-        gather(fb)
+        ctx.render_device(prm, rgb=f.rgb.data_ptr(), z=f.z.data_ptr(), sample_count=f.sample_count.data_ptr(),
+                          object_id=f.object_id.data_ptr())
+        gather(f)
         if rank == 0:
-            host_rgb.copy_(fb.rgb, non_blocking=True)
+            host_rgbs[k].copy_(f.rgb, non_blocking=True)
+            copied[k].record()
 
     def fence():
         if grouped:
