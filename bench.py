@@ -49,6 +49,7 @@ WORKLOADS = {
     "scene_a_720p_128spp": ("cornell", None, 1280, 720, 128),
     # Whitted-style shader (project-12 snapshot): Blinn-Phong + adaptive soft shadows, no recursion
     "spheres_1080p_16spp_whitted": ("spheres", 8, 1920, 1080, 16),
+    "spheres_1080p_16spp_path": ("spheres_path", 8, 1920, 1080, 16),  # the same scene through the path tracer
     # photon maps: 10M + 1M photons traced, balanced and gathered from, 16..64 spp adaptive, 5 bounces
     "photon_box_1080p": ("photons", (10_000_000, 1_000_000), 1920, 1080, (16, 64)),
     "photon_box_540p_small": ("photons", (1_000_000, 100_000), 960, 540, (16, 64)),  # development size
@@ -60,6 +61,7 @@ METRICS = {
     "mesh_10m_4k_adaptive": "Mrays/sec, 10M-tri 4K adaptive 16..256 spp path tracing",
     "scene_a_720p_128spp": "Mrays/sec, scene.xml as shipped (1280x720, 128 spp); ms_per_step is ms/frame scene.xml",
     "spheres_1080p_16spp_whitted": "Mrays/sec, sphere/plane scene 1080p 16 spp, Blinn-Phong + shadows",
+    "spheres_1080p_16spp_path": "Mrays/sec, sphere/plane scene 1080p 16 spp, path tracing (50 bounces)",
     "photon_box_1080p": "Mrays/sec, photon-mapped caustics scene 1080p, 10M + 1M photons traced and gathered",
     "photon_box_540p_small": "Mrays/sec, photon-mapped caustics scene 540p, 1M + 0.1M photons (development size)",
 }
@@ -73,6 +75,8 @@ def build_scene(name):
     spp = spp if isinstance(spp, tuple) else (spp, spp)
     if kind == "spheres":
         return lib.HostScene.from_string(scenes.spheres_scene_xml(grid=arg, width=w, height=h)), w, h, spp, 0, abi.RT_MODE_WHITTED, 0, None
+    if kind == "spheres_path":
+        return lib.HostScene.from_string(scenes.spheres_scene_xml(grid=arg, width=w, height=h)), w, h, spp, 0, abi.RT_MODE_PATH, 50, None
     if kind == "cornell":
         return lib.HostScene.from_string(scenes.cornell_scene_xml(w, h)), w, h, spp, 0, abi.RT_MODE_PATH, 50, None
     if kind == "photons":

@@ -175,7 +175,7 @@ struct WorkQueue {
 #define RT_PATHS_MIN_WAVES 3 // waves per SIMD the register allocator must leave room for: 170 registers.  The kernel runs the scenes without meshes (a scene with one goes through the wavefront pipeline), where it is bound by its own arithmetic: at 6 waves (80 registers) it spills 220 values and the reference's scene takes 65 ms, at 4: 56 ms, at 3: 38 ms, at 2: 46 ms
 #endif
 
-template <bool COUNT, int LEVELS, bool TEXBG>
+template <bool COUNT, int LEVELS, bool TEXBG, bool CULL = false>
 __global__ __launch_bounds__(kBlock, RT_PATHS_MIN_WAVES) void k_paths(DScene S, DFrame F, const float *__restrict__ halton,
                                                   const int32_t *__restrict__ active, uint64_t n_items, int k0, int nk,
                                                   float4 *__restrict__ sbuf, FramePlanes out, DCounters *ctr,
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(kBlock, RT_PATHS_MIN_WAVES) void k_paths(DScene S, 
         }
         pt.tock(4);
         if (alive) {
-            if (!path_step<COUNT, LEVELS, TEXBG>(S, F, ps, st, pt, tl, &fz, &fid)) {
+            if (!path_step<COUNT, LEVELS, TEXBG, CULL>(S, F, ps, st, pt, tl, &fz, &fid)) {
                 if (k == 0) {
                     if (out.z) out.z[pix] = fz;
                     if (out.object_id) out.object_id[pix] = fid;

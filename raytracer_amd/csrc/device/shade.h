@@ -237,7 +237,9 @@ RT_DEV void path_begin(PathState &ps, Ray ray)
 // One iteration of the bounce loop of tracePath (src/main.cpp:170-265).  Returns
 // false when the path has ended; ps.result then holds its radiance.  first_z /
 // first_id receive depth and node id of the camera ray's hit when non-null.
-template <bool COUNT, int LEVELS, bool TEXBG = true>
+// CULL: the scene walks skip objects whose world-space box no ray of the wave reaches (the hierarchy over the boxes
+// where the scene has one): which objects are looked at changes, no answer does.
+template <bool COUNT, int LEVELS, bool TEXBG = true, bool CULL = false>
 RT_DEV bool path_step(const DScene &S, const DFrame &F, PathState &ps, LaneStack st, PathTally &pt,
                       Tally<COUNT> &tl, float *first_z, int *first_id)
 {
@@ -250,7 +252,7 @@ RT_DEV bool path_step(const DScene &S, const DFrame &F, PathState &ps, LaneStack
     bool hit;
     pt.tick();
     ++pt.closest;
-    hit = trace_closest<COUNT, LEVELS>(S, ray, st, h, tl);
+    hit = trace_closest<COUNT, LEVELS, CULL>(S, ray, st, h, tl);
     pt.tock(0);
     if (ps.bounce == 0 && first_z) { *first_z = h.z; *first_id = hit ? h.node : -1; }
     if (!hit) {
@@ -290,7 +292,7 @@ RT_DEV bool path_step(const DScene &S, const DFrame &F, PathState &ps, LaneStack
         sr.d = ne.dir;
         ++pt.shadow;
         pt.tock(1);
-        const bool occluded = trace_shadow<COUNT, LEVELS>(S, sr, ne.dist - bias, st, tl);
+        const bool occluded = trace_shadow<COUNT, LEVELS, CULL>(S, sr, ne.dist - bias, st, tl);
         pt.tock(2);
         if (!occluded) {
             const float cosS = std_max(0.0f, dot(normal, sr.d));

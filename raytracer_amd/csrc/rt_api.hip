@@ -87,7 +87,7 @@ struct rt_ctx {
     size_t ovf_threads = 0;
     bool gpu_bvh = false;     // RT_GPU_BVH=1: build every mesh's BVH on the GPU even if the scene brings one
     double bvh_build_ms = 0;  // GPU time of the last upload's BVH builds
-    int tlas_min_objects = 8; // RT_TLAS_MIN: object nodes from which a scene gets the hierarchy over their boxes (0 = never)
+    int tlas_min_objects = 16; // RT_TLAS_MIN: object nodes from which a scene gets the hierarchy over their boxes (0 = never).  The reference's own scene (nine objects, five of them the walls of a box every ray is inside of) is slower through it: 38 -> 56 ms per frame
     int lds_levels_max = 13;
     int n_cu = 256;
     int ray_levels = 1; // hierarchy levels that have children
@@ -219,8 +219,18 @@ template <bool TEXBG> const void *paths_kernel_lockstep(bool counting, int ray_l
     return counting ? (const void *)k_paths<true, 5, TEXBG> : (const void *)k_paths<false, 5, TEXBG>;
 }
 
-const void *paths_kernel(bool counting, int ray_levels, bool textured_background)
+// the path kernel whose scene walks skip objects out of the wave's reach: scenes of many objects (not the counting
+// variant: its box and triangle tests are the reference's, which looks at every object)
+template <bool TEXBG> const void *paths_kernel_culling(int ray_levels)
 {
+    if (ray_levels <= 1) return (const void *)k_paths<false, 1, TEXBG, true>;
+    if (ray_levels == 2) return (const void *)k_paths<false, 2, TEXBG, true>;
+    return (const void *)k_paths<false, 5, TEXBG, true>;
+}
+
+const void *paths_kernel(bool counting, int ray_levels, bool textured_background, bool culling)
+{
+    if (culling && !counting) return textured_background ? paths_kernel_culling<true>(ray_levels) : paths_kernel_culling<false>(ray_levels);
     return textured_background ? paths_kernel_lockstep<true>(counting, ray_levels) : paths_kernel_lockstep<false>(counting, ray_levels);
 }
 
@@ -423,6 +433,8 @@ int rt_init(int device, rt_ctx **out)
                           (const void *)k_paths<true, 1, false>, (const void *)k_paths<true, 2, false>, (const void *)k_paths<true, 5, false>,
                           (const void *)k_paths<false, 1, true>, (const void *)k_paths<false, 2, true>, (const void *)k_paths<false, 5, true>,
                           (const void *)k_paths<true, 1, true>, (const void *)k_paths<true, 2, true>, (const void *)k_paths<true, 5, true>,
+                          (const void *)k_paths<false, 1, false, true>, (const void *)k_paths<false, 2, false, true>, (const void *)k_paths<false, 5, false, true>,
+                          (const void *)k_paths<false, 1, true, true>, (const void *)k_paths<false, 2, true, true>, (const void *)k_paths<false, 5, true, true>,
                           (const void *)k_rays<false, 1, WfIO>, (const void *)k_rays<false, 2, WfIO>, (const void *)k_rays<false, 5, WfIO>,
                           (const void *)k_rays<true, 1, WfIO>, (const void *)k_rays<true, 2, WfIO>, (const void *)k_rays<true, 5, WfIO>,
                           (const void *)k_whitted<false, 1>, (const void *)k_whitted<false, 2>, (const void *)k_whitted<false, 5>,
@@ -1196,7 +1208,7 @@ int rt_render(rt_ctx *ctx, const rt_render_params *prm, rt_frame_out *out)
                 F.chunk = per_wave >= 1024 ? 1024u : per_wave >= 512 ? 512u : 256u;
                 if (ctx->chunk_items > 0) F.chunk = (uint32_t)ctx->chunk_items;
             }
-            const void *fn = paths_kernel(ctx->counting, ctx->ray_levels, ctx->scene.background_texture > 0);
+            const void *fn = paths_kernel(ctx->counting, ctx->ray_levels, ctx->scene.background_texture > 0, ctx->scene.n_tlas > 0);
             int per_cu = 1;
             HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kBlock, lds));
             per_cu = std::max(1, std::min(per_cu, 8));

@@ -594,7 +594,7 @@ def test_multi_material_object_vs_reference(ctx, tmp_path, monkeypatch):
 
 
 def test_object_hierarchy_changes_nothing(monkeypatch, tmp_path):
-    """The Whitted kernel's scene walk through the hierarchy over the objects' world boxes (scenes of eight objects and
+    """The Whitted kernel's and the path kernel's scene walks through the hierarchy over the objects' world boxes (scenes of sixteen objects and
     more by default; RT_TLAS_MIN=1 here: every scene) against the walk over the flat node list (RT_TLAS_MIN=0): the
     hierarchy only decides which objects a wave looks at, so every plane is the same bit for bit - on the sphere grid,
     on nested transformations (objects met out of list order, local rays rebuilt through the ancestors), on the
@@ -608,13 +608,16 @@ def test_object_hierarchy_changes_nothing(monkeypatch, tmp_path):
         (lib.HostScene.from_string(scenes.cornell_scene_xml(128, 72)), 5, 2),
         (multi_material_scene(O.load_golden("whitted_multimtl_96x54_b5"), tmp_path), 2, 2),
     ]
+    # ... and the path kernel on the scenes without a mesh (a scene with one goes through the ray-list kernel)
+    cases += [(cases[0][0], -50, 4), (cases[2][0], -50, 4), (cases[3][0], -50, 8)]
     frames = {}
     for tlas_min in ("0", "1"):
         monkeypatch.setenv("RT_TLAS_MIN", tlas_min)
         c = lib.Context(0)
         try:
             for k, (hs, bounces, spp) in enumerate(cases):
-                prm = abi.default_params(seed=11 + k, min_spp=spp, max_spp=spp, max_bounces=bounces, mode=abi.RT_MODE_WHITTED)
+                prm = abi.default_params(seed=11 + k, min_spp=spp, max_spp=spp, max_bounces=abs(bounces),
+                                         mode=abi.RT_MODE_WHITTED if bounces >= 0 else abi.RT_MODE_PATH)
                 frames[tlas_min, k] = render_gpu(c, hs, prm, hs.camera.width, hs.camera.height)
         finally:
             c.close()
