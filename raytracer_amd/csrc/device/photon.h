@@ -139,8 +139,11 @@ constexpr uint64_t kSeedGlobalMap = 0x50484F54ULL, kSeedCausticsMap = 0x43415553
 // scans the counts into offsets, WRITE = true traces the same paths again (same streams, same
 // arithmetic) and writes photon `seq` of path `i` to out[offsets[i] + seq] if that is below
 // `capacity`.
+#ifndef RT_PHOTON_MIN_WAVES
+#define RT_PHOTON_MIN_WAVES 3 // waves per SIMD the register allocator must leave room for (1.1 M photons emitted in 9.3 / 6.9 / 5.6 / 5.5 ms at 6 / 4 / 3 / 2)
+#endif
 template <bool WRITE, int LEVELS>
-__global__ __launch_bounds__(kBlock, 4) void k_photon_paths(DScene S, rt_photon_params P, int which, uint64_t path_begin,
+__global__ __launch_bounds__(kBlock, RT_PHOTON_MIN_WAVES) void k_photon_paths(DScene S, rt_photon_params P, int which, uint64_t path_begin,
                                                             uint32_t n_paths, uint32_t *__restrict__ counts,
                                                             const uint32_t *__restrict__ offsets, uint64_t base,
                                                             rt_photon *__restrict__ out, uint64_t capacity, DCounters *ctr,
