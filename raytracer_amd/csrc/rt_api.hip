@@ -255,6 +255,14 @@ const void *wf_trace_kernel(bool counting, int ray_levels)
     return counting ? (const void *)k_rays<true, 5, WfIO> : (const void *)k_rays<false, 5, WfIO>;
 }
 
+// rays a wave of the ray-list kernel reserves per queue atomic: few atomics on the queue word in large launches, enough
+// portions for every wave (and an even end) in small ones - about an eighth of a wave's share of the list
+uint32_t ray_portion(uint64_t n_rays, unsigned grid_blocks)
+{
+    const uint64_t per_wave = n_rays / ((uint64_t)grid_blocks * (kBlock / 64)) / 8;
+    return per_wave >= 1024 ? 1024u : per_wave >= 512 ? 512u : per_wave >= 256 ? 256u : per_wave >= 128 ? 128u : 64u;
+}
+
 size_t stack_lds_bytes(const DScene &S) { return (size_t)S.lds_levels * kBlock * 8; }
 // kernels that look photons up keep the arrays of found photons of kGatherSlots lanes per wave behind the stacks
 size_t gather_lds_bytes(const DScene &S) { return stack_lds_bytes(S) + kHeapLdsBytes; }
@@ -321,8 +329,7 @@ static int render_wavefront(rt_ctx *ctx, const DFrame &F, const int32_t *act, ui
             WfIO a_io{P, queue_in, ctx->d_wf_sh_queue.as<uint32_t>(), n_ext};
             uint32_t a_n = (uint32_t)n_rays;
             // rays a wave reserves at a time: few atomics on the queue word in the large launches, enough chunks for every wave in the small ones
-            const uint64_t per_wave = n_rays / ((uint64_t)grid.x * (kBlock / 64)) / 8;
-            uint32_t a_chunk = per_wave >= 1024 ? 1024u : per_wave >= 512 ? 512u : per_wave >= 256 ? 256u : per_wave >= 128 ? 128u : 64u;
+            uint32_t a_chunk = ray_portion(n_rays, grid.x);
             void *targs[] = {&a_scene, &a_io, &a_n, &a_ctr, &a_queue, &a_chunk};
             HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue.p, 0, kQueueBytes, s));
             const bool timed = launch < rt_ctx::kMaxRayLaunches;
@@ -1432,7 +1439,7 @@ int rt_trace_brief(rt_ctx *ctx, const float *rays6, const float *t_max, int n, r
         uint32_t a_n = (uint32_t)n;
         DCounters *a_ctr = ctx->d_counters.as<DCounters>();
         unsigned long long *a_queue = ctx->d_queue.as<unsigned long long>();
-        uint32_t a_chunk = kRayChunk;
+        uint32_t a_chunk = ray_portion((uint64_t)n, grid.x);
         void *args[] = {&a_scene, &a_io, &a_n, &a_ctr, &a_queue, &a_chunk};
         HIP_TRY(ctx, hipEventRecord(ctx->evk0, s));
         HIP_TRY(ctx, hipLaunchKernel(fn, grid, dim3(kBlock), args, lds, s));
@@ -1492,7 +1499,7 @@ int rt_trace_brief_noalloc(rt_ctx *ctx, const float *d_rays6, const float *d_t_m
     uint32_t a_n = (uint32_t)n;
     DCounters *a_ctr = (DCounters *)(base + kStaticCountersOff);
     unsigned long long *a_queue = (unsigned long long *)(base + kStaticQueueOff);
-    uint32_t a_chunk = kRayChunk;
+    uint32_t a_chunk = ray_portion((uint64_t)n, grid.x);
     void *args[] = {&a_scene, &a_io, &a_n, &a_ctr, &a_queue, &a_chunk};
     HIP_TRY(ctx, hipEventRecord(ctx->evk0, s));
     HIP_TRY(ctx, hipLaunchKernel(fn, grid, dim3(kBlock), args, lds, s));
