@@ -316,13 +316,16 @@ constexpr uint32_t kFarIsLow = 0x80000000u, kFarDone = 0x40000000u;
 // A wave looks photons up for kGatherSlots of its lanes at a time: a lane takes part in round
 // (rank among the wave's lookups) / kGatherSlots with slot rank % kGatherSlots.  Entry e of slot s of wave w lies at
 // dist2[e - 1][w * kGatherSlots + s]: the LDS bank depends on the slot alone, whatever entries the lanes are at.
+#ifndef RT_HEAP_REG_LEVELS
+#define RT_HEAP_REG_LEVELS 1 // entries 1..7 of a full heap in registers
+#endif
 #ifndef RT_GATHER_SLOTS
 #define RT_GATHER_SLOTS 32
 #endif
 constexpr uint32_t kGatherSlots = RT_GATHER_SLOTS;
 static_assert(kGatherSlots == 8 || kGatherSlots == 16 || kGatherSlots == 32 || kGatherSlots == 64, "slots per wave: a power of two that keeps the LDS bank a function of the slot");
 constexpr uint32_t kHeapSlotStride = kGatherSlots * (kBlock / 64); // slots of a workgroup
-constexpr int kHeapLdsEntries = 63;                                 // whole levels: 1 + 2 + ... + 32
+constexpr int kHeapLdsEntries = 63;                                 // whole levels: 1 + 2 + ... + 32 (the replacement's rounds are written for this split)
 constexpr size_t kHeapLdsBytes = (size_t)kHeapLdsEntries * kHeapSlotStride * 5;
 constexpr uint32_t kHeapGlobalEntries = 66; // entries 64..128 and one of padding: pairs are read with one 16-byte load
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -343,6 +346,17 @@ struct LaneHeap {
     {
         if (e <= kHeapLdsEntries) { d2[(uint32_t)(e - 1) * kHeapSlotStride] = __uint_as_float(v.x); tag[(uint32_t)(e - 1) * kHeapSlotStride] = (uint8_t)v.y; }
         else g[e - 64] = v;
+    }
+    RT_DEV u32x4 lds_pair(int j) const // j even, j + 1 <= 63
+    {
+        const uint32_t o = (uint32_t)(j - 1) * kHeapSlotStride;
+        return u32x4{__float_as_uint(d2[o]), tag[o], __float_as_uint(d2[o + kHeapSlotStride]), tag[o + kHeapSlotStride]};
+    }
+    RT_DEV u32x4 global_pair(int j) const { return *(GH4)&g[j - 64]; } // j even, j >= 64
+    RT_DEV void lds_put(int e, float dist2, uint32_t place) const
+    {
+        d2[(uint32_t)(e - 1) * kHeapSlotStride] = dist2;
+        tag[(uint32_t)(e - 1) * kHeapSlotStride] = (uint8_t)place;
     }
     // entries j and j + 1, j even: both on the same side of the boundary
     RT_DEV u32x4 pair(int j) const
@@ -404,6 +418,10 @@ struct KdStack {
     }
 };
 
+#ifdef RT_GATHER_TIMING
+__device__ unsigned long long g_gather_diag[24];
+#define GT_NOW() ((unsigned long long)__builtin_readcyclecounter())
+#endif
 template <bool COUNT>
 RT_DEV V3 photon_irradiance(const rt_photon *tree0, uint32_t n, V3 pos, V3 normal, float radius, KdStack st,
                             const LaneHeap H, uint32_t &visits)
@@ -417,11 +435,32 @@ RT_DEV V3 photon_irradiance(const rt_photon *tree0, uint32_t n, V3 pos, V3 norma
     int sp = 0;
     uint32_t cur = 1;
     bool going_down = true;
+#if RT_HEAP_REG_LEVELS
+    float top2[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // entries 1..7 of the full heap: dist2 and place
+    uint32_t ttag[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+#ifdef RT_GATHER_TIMING
+    unsigned long long gt_trips = 0, gt_fetch = 0, gt_accept = 0, gt_accept_trips = 0, gt_build = 0, gt_back = 0, gt_down = 0, gt_sum = 0, gt_lanes = 0, gt_acc_lanes = 0, gt_append = 0, gt_heapify = 0, gt_replace = 0;
+    const unsigned long long gt_start = GT_NOW();
+#endif
     // One node per trip, whichever way the lane is going, so that the lanes of a wave stay together: on the way down
     // an inner node is passed (its far side noted on the stack); a leaf, or a node come back to from below, has its
     // own photon looked at, and then the walk backs up by one stack entry.
     for (;;) {
+#ifdef RT_GATHER_TIMING
+        const unsigned long long gt_t0 = GT_NOW();
+        ++gt_trips;
+        gt_lanes += (unsigned long long)__popcll(__ballot(1));
+#endif
         const f4 q0 = tree[2 * cur], q1 = tree[2 * cur + 1];
+#ifdef RT_GATHER_TIMING
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long gt_t1 = GT_NOW();
+        gt_fetch += gt_t1 - gt_t0;
+#endif
+#ifdef RT_GATHER_TIMING
+        bool gt_descended = false;
+#endif
         if (going_down && (int)cur < half) {
             const uint32_t axis = (__float_as_uint(q1.w) >> 24) & 3u;
             const float split = axis == 0 ? q0.x : (axis == 1 ? q0.y : q0.z);
@@ -432,18 +471,40 @@ RT_DEV V3 photon_irradiance(const rt_photon *tree0, uint32_t n, V3 pos, V3 norma
             ++sp;
             if (COUNT) ++visits;
             cur = high_first ? 2 * cur + 1 : 2 * cur;
+#ifdef RT_GATHER_TIMING
+            gt_descended = true;
+#else
             continue;
+#endif
         }
+#ifdef RT_GATHER_TIMING
+        unsigned long long gt_t2 = GT_NOW();
+        gt_down += gt_t2 - gt_t1;
+        if (!gt_descended) {
+#endif
         if (COUNT && going_down) ++visits;
         { // the node's own photon (src/photonmap.h:357-413)
             const uint32_t node = cur;
             const V3 dif = mk(q0.x, q0.y, q0.z) - pos;
             const float dist2 = len2(dif);
+#ifdef RT_GATHER_TIMING
+            const bool gt_acc = dist2 < lim && !(dot(mk(q1.x, q1.y, q1.z), normal) >= 0.0f);
+            const unsigned long long gt_b = __ballot(gt_acc);
+            gt_accept_trips += gt_b != 0;
+            gt_acc_lanes += gt_acc;
+#endif
             if (dist2 < lim && !(dot(mk(q1.x, q1.y, q1.z), normal) >= 0.0f)) {
                 if (found < kGatherK) {
+#ifdef RT_GATHER_TIMING
+                    const unsigned long long gt_a0 = GT_NOW();
+#endif
                     H.ids[found] = node;
                     ++found;
                     H.put(found, u32x2{__float_as_uint(dist2), (uint32_t)(found - 1)});
+#ifdef RT_GATHER_TIMING
+                    const unsigned long long gt_a1 = GT_NOW();
+                    gt_append += gt_a1 - gt_a0;
+#endif
                     if (found == kGatherK) { // build the max-heap
                         const int half_found = found >> 1;
                         for (int k = half_found; k >= 1; --k) {
@@ -462,12 +523,111 @@ RT_DEV V3 photon_irradiance(const rt_photon *tree0, uint32_t n, V3 pos, V3 norma
                             }
                             H.put(parent, t);
                         }
+#if RT_HEAP_REG_LEVELS
+#pragma unroll
+                        for (int k = 1; k < 8; ++k) { const u32x2 e = H.get(k); top2[k] = __uint_as_float(e.x); ttag[k] = e.y; }
+#endif
+#ifdef RT_GATHER_TIMING
+                        gt_heapify += GT_NOW() - gt_a1;
+#endif
                     }
                 } else { // replace the farthest; the newcomer takes over its place in the id table
+#ifdef RT_GATHER_TIMING
+                    ++gt_build;
+                    const unsigned long long gt_r0 = GT_NOW();
+#endif
+#if RT_HEAP_REG_LEVELS
+                    // the three levels every replacement passes are in registers (top[1..7]); selects, no memory
+                    const uint32_t place = ttag[1];
+                    H.ids[place] = node;
+                    bool placed = false;
+                    int parent;
+                    { // entry 1 against entries 2, 3
+                        const bool right = top2[2] < top2[3];
+                        const float dj = right ? top2[3] : top2[2];
+                        const uint32_t ij = right ? ttag[3] : ttag[2];
+                        placed = dist2 > dj;
+                        top2[1] = placed ? dist2 : dj;
+                        ttag[1] = placed ? place : ij;
+                        parent = right ? 3 : 2;
+                    }
+                    { // entry 2 or 3 against its children among 4..7
+                        const bool low = parent == 2;
+                        const float c0 = low ? top2[4] : top2[6], c1 = low ? top2[5] : top2[7];
+                        const uint32_t i0 = low ? ttag[4] : ttag[6], i1 = low ? ttag[5] : ttag[7];
+                        const bool right = c0 < c1;
+                        const float dj = right ? c1 : c0;
+                        const uint32_t ij = right ? i1 : i0;
+                        const bool here = !placed && dist2 > dj; // the newcomer stays at `parent`
+                        const float v = here ? dist2 : dj;
+                        const uint32_t vi = here ? place : ij;
+                        if (!placed) {
+                            top2[2] = low ? v : top2[2]; ttag[2] = low ? vi : ttag[2];
+                            top2[3] = low ? top2[3] : v; ttag[3] = low ? ttag[3] : vi;
+                        }
+                        placed = placed || here;
+                        parent = 2 * parent + (right ? 1 : 0);
+                    }
+                    // Below the registers two levels are decided per round trip: the children of the entry and all four
+                    // grandchildren are read at once (8..15 and 16..31 from LDS; then 32..63 from LDS together with
+                    // 64..127 from global memory).
+                    if (!placed) { // entry 4..7 (registers) against 8..15, the winner against its children among 16..31
+                        const int c = 2 * parent;
+                        const u32x4 ch = H.lds_pair(c), g01 = H.lds_pair(2 * c), g23 = H.lds_pair(2 * c + 2);
+                        const bool r1 = __uint_as_float(ch.x) < __uint_as_float(ch.z);
+                        const float d1 = r1 ? __uint_as_float(ch.z) : __uint_as_float(ch.x);
+                        const uint32_t t1 = r1 ? ch.w : ch.y;
+                        const bool here0 = dist2 > d1;
+                        const float v = here0 ? dist2 : d1;
+                        const uint32_t vi = here0 ? place : t1;
+#pragma unroll
+                        for (int k = 4; k < 8; ++k) {
+                            top2[k] = parent == k ? v : top2[k];
+                            ttag[k] = parent == k ? vi : ttag[k];
+                        }
+                        placed = here0;
+                        if (!here0) {
+                            const int j1 = c + (r1 ? 1 : 0);
+                            const u32x4 gg = r1 ? g23 : g01;
+                            const bool r2 = __uint_as_float(gg.x) < __uint_as_float(gg.z);
+                            const float d2_ = r2 ? __uint_as_float(gg.z) : __uint_as_float(gg.x);
+                            const uint32_t t2 = r2 ? gg.w : gg.y;
+                            const bool here1 = dist2 > d2_;
+                            H.lds_put(j1, here1 ? dist2 : d2_, here1 ? place : t2);
+                            placed = here1;
+                            parent = 2 * j1 + (r2 ? 1 : 0);
+                        }
+                    }
+                    if (!placed) { // entry 16..31 against 32..63 (LDS), the winner against its children among 64..127 (global)
+                        const int c = 2 * parent;
+                        const u32x4 g01 = H.global_pair(2 * c), g23 = H.global_pair(2 * c + 2);
+                        const u32x4 ch = H.lds_pair(c);
+                        const bool r1 = __uint_as_float(ch.x) < __uint_as_float(ch.z);
+                        const float d1 = r1 ? __uint_as_float(ch.z) : __uint_as_float(ch.x);
+                        const uint32_t t1 = r1 ? ch.w : ch.y;
+                        const bool here0 = dist2 > d1;
+                        H.lds_put(parent, here0 ? dist2 : d1, here0 ? place : t1);
+                        placed = here0;
+                        if (!here0) {
+                            const int j1 = c + (r1 ? 1 : 0);
+                            const u32x4 gg = r1 ? g23 : g01;
+                            const bool r2 = __uint_as_float(gg.x) < __uint_as_float(gg.z);
+                            const float d2_ = r2 ? __uint_as_float(gg.z) : __uint_as_float(gg.x);
+                            const uint32_t t2 = r2 ? gg.w : gg.y;
+                            const bool here1 = dist2 > d2_;
+                            H.lds_put(j1, here1 ? dist2 : d2_, here1 ? place : t2);
+                            placed = here1;
+                            parent = 2 * j1 + (r2 ? 1 : 0);
+                        }
+                    }
+                    float top = top2[1];
+                    int j = placed ? found + 1 : 2 * parent;
+#else
                     const uint32_t place = H.get(1).y;
                     H.ids[place] = node;
                     int parent = 1, j = 2;
                     float top = dist2; // what ends up in entry 1
+#endif
                     while (j <= found) {
                         const u32x4 c = H.pair(j);
                         float dj = __uint_as_float(c.x);
@@ -478,12 +638,27 @@ RT_DEV V3 photon_irradiance(const rt_photon *tree0, uint32_t n, V3 pos, V3 norma
                         if (parent == 1) top = dj;
                         parent = j;
                         j <<= 1;
+#ifdef RT_GATHER_TIMING
+                        ++gt_sum;
+#endif
                     }
+#if RT_HEAP_REG_LEVELS
+                    if (!placed)
+#endif
                     H.put(parent, u32x2{__float_as_uint(dist2), place});
                     lim = top;
+#ifdef RT_GATHER_TIMING
+                    gt_replace += GT_NOW() - gt_r0;
+#endif
                 }
             }
         }
+#ifdef RT_GATHER_TIMING
+        }
+        const unsigned long long gt_t3 = GT_NOW();
+        gt_accept += gt_t3 - gt_t2;
+        if (!gt_descended) {
+#endif
         // back up: the parent's far child if it can still hold something closer, else the parent's own photon
         if (sp == 0) break;
         uint32_t data; float plane2;
@@ -498,19 +673,69 @@ RT_DEV V3 photon_irradiance(const rt_photon *tree0, uint32_t n, V3 pos, V3 norma
             cur = parent;
             going_down = false;
         }
+#ifdef RT_GATHER_TIMING
+        }
+        gt_back += GT_NOW() - gt_t3;
+#endif
     }
+#ifdef RT_GATHER_TIMING
+    const unsigned long long gt_loop_end = GT_NOW();
+#endif
+#if RT_HEAP_REG_LEVELS
+    if (found == kGatherK) {
+#pragma unroll
+        for (int k = 1; k < 8; ++k) H.put(k, u32x2{__float_as_uint(top2[k]), ttag[k]});
+    }
+#endif
+    // the sum runs in array order; the three dependent reads per entry (place, photon id, photon) are issued for eight
+    // entries at a time
     V3 sum = mk(0, 0, 0);
-    for (int i = 1; i <= found; ++i) {
-        const uint32_t id = H.ids[H.get(i).y];
-        const f4 q0 = tree[2 * id], q1 = tree[2 * id + 1];
-        const uint32_t rgb = __float_as_uint(q1.w);
-        const V3 col = mk((float)(rgb & 255u) / 255.0f, (float)((rgb >> 8) & 255u) / 255.0f, (float)((rgb >> 16) & 255u) / 255.0f);
-        sum = sum + col * q0.w; // Color24::ToColor() * power, constant filter
+    const RT_GLOBAL_AS float *treef = (const RT_GLOBAL_AS float *)(const void *)tree0;
+    for (int i0 = 1; i0 <= found; i0 += 8) {
+        uint32_t place[8], id[8], rgb[8];
+        float power[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) place[u] = H.get(i0 + u <= found ? i0 + u : found).y;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) id[u] = H.ids[place[u]];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { // node i = floats 8 (i - 1) ..: power at 3, packed colour at 7
+            power[u] = treef[(size_t)(id[u] - 1u) * 8u + 3u];
+            rgb[u] = __float_as_uint(treef[(size_t)(id[u] - 1u) * 8u + 7u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (i0 + u > found) break;
+            const V3 col = mk((float)(rgb[u] & 255u) / 255.0f, (float)((rgb[u] >> 8) & 255u) / 255.0f, (float)((rgb[u] >> 16) & 255u) / 255.0f);
+            sum = sum + col * power[u]; // Color24::ToColor() * power, constant filter
+        }
     }
     if (found > 0) {
         const float area = kPi * lim;
         if (area > 0.0f) sum = sum * (1.0f / area);
     }
+#ifdef RT_GATHER_TIMING
+    {
+        const unsigned long long gt_end = GT_NOW();
+        atomicAdd(&g_gather_diag[0], 1ull);
+        atomicAdd(&g_gather_diag[1], gt_trips);
+        atomicAdd(&g_gather_diag[2], gt_loop_end - gt_start);
+        atomicAdd(&g_gather_diag[3], gt_fetch);
+        atomicAdd(&g_gather_diag[4], gt_down);
+        atomicAdd(&g_gather_diag[5], gt_accept);
+        atomicAdd(&g_gather_diag[6], gt_back);
+        atomicAdd(&g_gather_diag[7], gt_end - gt_loop_end + (sum.x == 123.0f));
+        atomicAdd(&g_gather_diag[8], gt_accept_trips);
+        atomicAdd(&g_gather_diag[9], gt_lanes);
+        atomicAdd(&g_gather_diag[10], gt_acc_lanes);
+        atomicAdd(&g_gather_diag[11], (unsigned long long)found);
+        atomicAdd(&g_gather_diag[12], gt_build);
+        atomicAdd(&g_gather_diag[13], gt_sum);
+        atomicAdd(&g_gather_diag[14], gt_append);
+        atomicAdd(&g_gather_diag[15], gt_replace);
+        atomicAdd(&g_gather_diag[16], gt_heapify);
+    }
+#endif
     return sum;
 }
 
