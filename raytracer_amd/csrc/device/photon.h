@@ -388,17 +388,18 @@ RT_DEV LaneHeap lane_heap(const DScene &S, uint32_t *lds, uint32_t slot)
 // levels are the ones in LDS and the levels next to the root go to the lane's overflow array if the tree is taller.
 struct KdStack {
     LaneStack st;
-    u32x2 *wave_lds; // level 0 of lane 0 of this wave
+    typedef __attribute__((address_space(3))) u32x2 *LdsEntry; // named address space: the pop must not wait for the heap's global stores
+    LdsEntry wave_lds; // level 0 of lane 0 of this wave
     uint32_t slot;
     uint32_t capacity; // kd levels the LDS storage holds
     uint32_t base;     // first level kept in LDS = levels that live in the overflow array
     RT_DEV KdStack(const LaneStack &s, uint32_t *lds, uint32_t slot_) : st(s), slot(slot_), base(0)
     {
-        wave_lds = (u32x2 *)lds + (threadIdx.x & ~63u);
+        wave_lds = (LdsEntry)((u32x2 *)lds + (threadIdx.x & ~63u));
         capacity = s.lds_levels * (64u / kGatherSlots);
     }
     RT_DEV void set_height(uint32_t height) { base = height > capacity ? height - capacity : 0u; }
-    RT_DEV u32x2 *at(uint32_t level) const
+    RT_DEV LdsEntry at(uint32_t level) const
     {
         constexpr uint32_t per = 64u / kGatherSlots;
         return wave_lds + (level / per) * kStackStride + (level % per) * kGatherSlots + slot;
@@ -418,10 +419,6 @@ struct KdStack {
     }
 };
 
-#ifdef RT_GATHER_TIMING
-__device__ unsigned long long g_gather_diag[24];
-#define GT_NOW() ((unsigned long long)__builtin_readcyclecounter())
-#endif
 template <bool COUNT>
 RT_DEV V3 photon_irradiance(const rt_photon *tree0, uint32_t n, V3 pos, V3 normal, float radius, KdStack st,
                             const LaneHeap H, uint32_t &visits)
@@ -439,28 +436,11 @@ RT_DEV V3 photon_irradiance(const rt_photon *tree0, uint32_t n, V3 pos, V3 norma
     float top2[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // entries 1..7 of the full heap: dist2 and place
     uint32_t ttag[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
-#ifdef RT_GATHER_TIMING
-    unsigned long long gt_trips = 0, gt_fetch = 0, gt_accept = 0, gt_accept_trips = 0, gt_build = 0, gt_back = 0, gt_down = 0, gt_sum = 0, gt_lanes = 0, gt_acc_lanes = 0, gt_append = 0, gt_heapify = 0, gt_replace = 0;
-    const unsigned long long gt_start = GT_NOW();
-#endif
     // One node per trip, whichever way the lane is going, so that the lanes of a wave stay together: on the way down
     // an inner node is passed (its far side noted on the stack); a leaf, or a node come back to from below, has its
     // own photon looked at, and then the walk backs up by one stack entry.
     for (;;) {
-#ifdef RT_GATHER_TIMING
-        const unsigned long long gt_t0 = GT_NOW();
-        ++gt_trips;
-        gt_lanes += (unsigned long long)__popcll(__ballot(1));
-#endif
         const f4 q0 = tree[2 * cur], q1 = tree[2 * cur + 1];
-#ifdef RT_GATHER_TIMING
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned long long gt_t1 = GT_NOW();
-        gt_fetch += gt_t1 - gt_t0;
-#endif
-#ifdef RT_GATHER_TIMING
-        bool gt_descended = false;
-#endif
         if (going_down && (int)cur < half) {
             const uint32_t axis = (__float_as_uint(q1.w) >> 24) & 3u;
             const float split = axis == 0 ? q0.x : (axis == 1 ? q0.y : q0.z);
@@ -471,40 +451,18 @@ RT_DEV V3 photon_irradiance(const rt_photon *tree0, uint32_t n, V3 pos, V3 norma
             ++sp;
             if (COUNT) ++visits;
             cur = high_first ? 2 * cur + 1 : 2 * cur;
-#ifdef RT_GATHER_TIMING
-            gt_descended = true;
-#else
             continue;
-#endif
         }
-#ifdef RT_GATHER_TIMING
-        unsigned long long gt_t2 = GT_NOW();
-        gt_down += gt_t2 - gt_t1;
-        if (!gt_descended) {
-#endif
         if (COUNT && going_down) ++visits;
         { // the node's own photon (src/photonmap.h:357-413)
             const uint32_t node = cur;
             const V3 dif = mk(q0.x, q0.y, q0.z) - pos;
             const float dist2 = len2(dif);
-#ifdef RT_GATHER_TIMING
-            const bool gt_acc = dist2 < lim && !(dot(mk(q1.x, q1.y, q1.z), normal) >= 0.0f);
-            const unsigned long long gt_b = __ballot(gt_acc);
-            gt_accept_trips += gt_b != 0;
-            gt_acc_lanes += gt_acc;
-#endif
             if (dist2 < lim && !(dot(mk(q1.x, q1.y, q1.z), normal) >= 0.0f)) {
                 if (found < kGatherK) {
-#ifdef RT_GATHER_TIMING
-                    const unsigned long long gt_a0 = GT_NOW();
-#endif
                     H.ids[found] = node;
                     ++found;
                     H.put(found, u32x2{__float_as_uint(dist2), (uint32_t)(found - 1)});
-#ifdef RT_GATHER_TIMING
-                    const unsigned long long gt_a1 = GT_NOW();
-                    gt_append += gt_a1 - gt_a0;
-#endif
                     if (found == kGatherK) { // build the max-heap
                         const int half_found = found >> 1;
                         for (int k = half_found; k >= 1; --k) {
@@ -527,15 +485,8 @@ RT_DEV V3 photon_irradiance(const rt_photon *tree0, uint32_t n, V3 pos, V3 norma
 #pragma unroll
                         for (int k = 1; k < 8; ++k) { const u32x2 e = H.get(k); top2[k] = __uint_as_float(e.x); ttag[k] = e.y; }
 #endif
-#ifdef RT_GATHER_TIMING
-                        gt_heapify += GT_NOW() - gt_a1;
-#endif
                     }
                 } else { // replace the farthest; the newcomer takes over its place in the id table
-#ifdef RT_GATHER_TIMING
-                    ++gt_build;
-                    const unsigned long long gt_r0 = GT_NOW();
-#endif
 #if RT_HEAP_REG_LEVELS
                     // the three levels every replacement passes are in registers (top[1..7]); selects, no memory
                     const uint32_t place = ttag[1];
@@ -638,27 +589,15 @@ RT_DEV V3 photon_irradiance(const rt_photon *tree0, uint32_t n, V3 pos, V3 norma
                         if (parent == 1) top = dj;
                         parent = j;
                         j <<= 1;
-#ifdef RT_GATHER_TIMING
-                        ++gt_sum;
-#endif
                     }
 #if RT_HEAP_REG_LEVELS
                     if (!placed)
 #endif
                     H.put(parent, u32x2{__float_as_uint(dist2), place});
                     lim = top;
-#ifdef RT_GATHER_TIMING
-                    gt_replace += GT_NOW() - gt_r0;
-#endif
                 }
             }
         }
-#ifdef RT_GATHER_TIMING
-        }
-        const unsigned long long gt_t3 = GT_NOW();
-        gt_accept += gt_t3 - gt_t2;
-        if (!gt_descended) {
-#endif
         // back up: the parent's far child if it can still hold something closer, else the parent's own photon
         if (sp == 0) break;
         uint32_t data; float plane2;
@@ -673,14 +612,7 @@ RT_DEV V3 photon_irradiance(const rt_photon *tree0, uint32_t n, V3 pos, V3 norma
             cur = parent;
             going_down = false;
         }
-#ifdef RT_GATHER_TIMING
-        }
-        gt_back += GT_NOW() - gt_t3;
-#endif
     }
-#ifdef RT_GATHER_TIMING
-    const unsigned long long gt_loop_end = GT_NOW();
-#endif
 #if RT_HEAP_REG_LEVELS
     if (found == kGatherK) {
 #pragma unroll
@@ -714,28 +646,6 @@ RT_DEV V3 photon_irradiance(const rt_photon *tree0, uint32_t n, V3 pos, V3 norma
         const float area = kPi * lim;
         if (area > 0.0f) sum = sum * (1.0f / area);
     }
-#ifdef RT_GATHER_TIMING
-    {
-        const unsigned long long gt_end = GT_NOW();
-        atomicAdd(&g_gather_diag[0], 1ull);
-        atomicAdd(&g_gather_diag[1], gt_trips);
-        atomicAdd(&g_gather_diag[2], gt_loop_end - gt_start);
-        atomicAdd(&g_gather_diag[3], gt_fetch);
-        atomicAdd(&g_gather_diag[4], gt_down);
-        atomicAdd(&g_gather_diag[5], gt_accept);
-        atomicAdd(&g_gather_diag[6], gt_back);
-        atomicAdd(&g_gather_diag[7], gt_end - gt_loop_end + (sum.x == 123.0f));
-        atomicAdd(&g_gather_diag[8], gt_accept_trips);
-        atomicAdd(&g_gather_diag[9], gt_lanes);
-        atomicAdd(&g_gather_diag[10], gt_acc_lanes);
-        atomicAdd(&g_gather_diag[11], (unsigned long long)found);
-        atomicAdd(&g_gather_diag[12], gt_build);
-        atomicAdd(&g_gather_diag[13], gt_sum);
-        atomicAdd(&g_gather_diag[14], gt_append);
-        atomicAdd(&g_gather_diag[15], gt_replace);
-        atomicAdd(&g_gather_diag[16], gt_heapify);
-    }
-#endif
     return sum;
 }
 

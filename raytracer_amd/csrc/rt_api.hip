@@ -1843,16 +1843,6 @@ int rt_photons_irradiance(rt_ctx *ctx, int which, const float *pos3, const float
     HIP_TRY(ctx, hipStreamSynchronize(s));
     if (int rc = batch_time(ctx)) return rc;
     ctx->counters.gathers = dc.gathers; ctx->counters.photon_visits = dc.photon_visits;
-#ifdef RT_GATHER_TIMING
-    {
-        unsigned long long d[24] = {}, z[24] = {};
-        (void)hipMemcpyFromSymbol(d, HIP_SYMBOL(g_gather_diag), sizeof d);
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gather_diag), z, sizeof z);
-        const double q = (double)d[0];
-        fprintf(stderr, "gather timing per lookup: trips %.0f, loop %.0f cyc (fetch %.0f, down %.0f, photon+heap %.0f, back %.0f), sum %.0f cyc; trips with an acceptance %.0f, lanes per trip %.1f, accepted per lookup %.0f, found %.0f, replacements %.0f with %.1f levels each; appends %.0f cyc, replacements %.0f cyc, heap build %.0f cyc\n",
-                d[1] / q, d[2] / q, d[3] / q, d[4] / q, d[5] / q, d[6] / q, d[7] / q, d[8] / q, (double)d[9] / d[1], d[10] / q, d[11] / q, d[12] / q, (double)d[13] / (double)(d[12] ? d[12] : 1), d[14] / q, d[15] / q, d[16] / q);
-    }
-#endif
     return RT_OK;
 }
 
