@@ -454,6 +454,9 @@ RT_DEV V3 photon_irradiance(const rt_photon *tree0, uint32_t n, V3 pos, V3 norma
             continue;
         }
         if (COUNT && going_down) ++visits;
+        // the entry the walk backs up to is read now: its latency passes while the photon is looked at and entered
+        uint32_t data = 0; float plane2 = 0.0f;
+        if (sp > 0) st.pop(sp - 1, data, plane2);
         { // the node's own photon (src/photonmap.h:357-413)
             const uint32_t node = cur;
             const V3 dif = mk(q0.x, q0.y, q0.z) - pos;
@@ -600,8 +603,6 @@ RT_DEV V3 photon_irradiance(const rt_photon *tree0, uint32_t n, V3 pos, V3 norma
         }
         // back up: the parent's far child if it can still hold something closer, else the parent's own photon
         if (sp == 0) break;
-        uint32_t data; float plane2;
-        st.pop(sp - 1, data, plane2);
         const uint32_t parent = data & 0x3FFFFFFFu;
         if (!(data & kFarDone) && plane2 < lim) {
             st.push(sp - 1, data | kFarDone, plane2);
