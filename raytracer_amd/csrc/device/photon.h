@@ -316,9 +316,6 @@ constexpr uint32_t kFarIsLow = 0x80000000u, kFarDone = 0x40000000u;
 // A wave looks photons up for kGatherSlots of its lanes at a time: a lane takes part in round
 // (rank among the wave's lookups) / kGatherSlots with slot rank % kGatherSlots.  Entry e of slot s of wave w lies at
 // dist2[e - 1][w * kGatherSlots + s]: the LDS bank depends on the slot alone, whatever entries the lanes are at.
-#ifndef RT_HEAP_REG_LEVELS
-#define RT_HEAP_REG_LEVELS 1 // entries 1..7 of a full heap in registers
-#endif
 #ifndef RT_GATHER_SLOTS
 #define RT_GATHER_SLOTS 32
 #endif
@@ -327,6 +324,7 @@ static_assert(kGatherSlots == 8 || kGatherSlots == 16 || kGatherSlots == 32 || k
 constexpr uint32_t kHeapSlotStride = kGatherSlots * (kBlock / 64); // slots of a workgroup
 constexpr int kHeapLdsEntries = 63;                                 // whole levels: 1 + 2 + ... + 32 (the replacement's rounds are written for this split)
 constexpr size_t kHeapLdsBytes = (size_t)kHeapLdsEntries * kHeapSlotStride * 5;
+static_assert(kGatherK == 128, "the replacement's rounds are written for a heap of seven levels and entry 128");
 constexpr uint32_t kHeapGlobalEntries = 66; // entries 64..128 and one of padding: pairs are read with one 16-byte load
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 struct LaneHeap {
@@ -432,10 +430,8 @@ RT_DEV V3 photon_irradiance(const rt_photon *tree0, uint32_t n, V3 pos, V3 norma
     int sp = 0;
     uint32_t cur = 1;
     bool going_down = true;
-#if RT_HEAP_REG_LEVELS
     float top2[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // entries 1..7 of the full heap: dist2 and place
     uint32_t ttag[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#endif
     // One node per trip, whichever way the lane is going, so that the lanes of a wave stay together: on the way down
     // an inner node is passed (its far side noted on the stack); a leaf, or a node come back to from below, has its
     // own photon looked at, and then the walk backs up by one stack entry.
@@ -484,13 +480,10 @@ RT_DEV V3 photon_irradiance(const rt_photon *tree0, uint32_t n, V3 pos, V3 norma
                             }
                             H.put(parent, t);
                         }
-#if RT_HEAP_REG_LEVELS
 #pragma unroll
                         for (int k = 1; k < 8; ++k) { const u32x2 e = H.get(k); top2[k] = __uint_as_float(e.x); ttag[k] = e.y; }
-#endif
                     }
                 } else { // replace the farthest; the newcomer takes over its place in the id table
-#if RT_HEAP_REG_LEVELS
                     // the three levels every replacement passes are in registers (top[1..7]); selects, no memory
                     const uint32_t place = ttag[1];
                     H.ids[place] = node;
@@ -574,30 +567,19 @@ RT_DEV V3 photon_irradiance(const rt_photon *tree0, uint32_t n, V3 pos, V3 norma
                             parent = 2 * j1 + (r2 ? 1 : 0);
                         }
                     }
-                    float top = top2[1];
                     int j = placed ? found + 1 : 2 * parent;
-#else
-                    const uint32_t place = H.get(1).y;
-                    H.ids[place] = node;
-                    int parent = 1, j = 2;
-                    float top = dist2; // what ends up in entry 1
-#endif
-                    while (j <= found) {
+                    while (j <= found) { // what is left: entry 64 against entry 128
                         const u32x4 c = H.pair(j);
                         float dj = __uint_as_float(c.x);
                         uint32_t ij = c.y;
                         if (j < found && dj < __uint_as_float(c.z)) { ++j; dj = __uint_as_float(c.z); ij = c.w; }
                         if (dist2 > dj) break;
                         H.put(parent, u32x2{__float_as_uint(dj), ij});
-                        if (parent == 1) top = dj;
                         parent = j;
                         j <<= 1;
                     }
-#if RT_HEAP_REG_LEVELS
-                    if (!placed)
-#endif
-                    H.put(parent, u32x2{__float_as_uint(dist2), place});
-                    lim = top;
+                    if (!placed) H.put(parent, u32x2{__float_as_uint(dist2), place});
+                    lim = top2[1];
                 }
             }
         }
@@ -614,12 +596,10 @@ RT_DEV V3 photon_irradiance(const rt_photon *tree0, uint32_t n, V3 pos, V3 norma
             going_down = false;
         }
     }
-#if RT_HEAP_REG_LEVELS
     if (found == kGatherK) {
 #pragma unroll
         for (int k = 1; k < 8; ++k) H.put(k, u32x2{__float_as_uint(top2[k]), ttag[k]});
     }
-#endif
     // the sum runs in array order; the three dependent reads per entry (place, photon id, photon) are issued for eight
     // entries at a time
     V3 sum = mk(0, 0, 0);
