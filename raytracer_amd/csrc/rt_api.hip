@@ -363,8 +363,9 @@ static int render_wavefront(rt_ctx *ctx, const DFrame &F, const int32_t *act, ui
             queue_in = queue_out;
             cur ^= 1;
         }
-        uint32_t got[2] = {0, 0};
-        HIP_TRY(ctx, hipMemcpyAsync(got, counts, 8, hipMemcpyDeviceToHost, s));
+        // the two list lengths, into pinned memory (a pageable destination goes through a staging copy)
+        volatile uint32_t *got = (volatile uint32_t *)&ctx->host_words[2];
+        HIP_TRY(ctx, hipMemcpyAsync((void *)got, counts, 8, hipMemcpyDeviceToHost, s));
         HIP_TRY(ctx, hipStreamSynchronize(s));
         n_ext = got[0]; n_sh = got[1];
         ctx->prog_round_done.store(items - n_ext); // paths that have ended
