@@ -37,7 +37,10 @@ struct Hit {
 constexpr uint32_t kStackStride = 256;
 // The stack is reached through generic pointers (flat instructions).  Naming the two address spaces
 // (RT_STACK_TYPED: ds_read/ds_write for the LDS levels, global_load/store for the overflow) looks like
-// the obvious thing to do but measured 2-4 % slower in every kernel here, so it stays a switch.
+// the obvious thing to do; measured, it is 1 % faster in the path tracer's kernels (1M-triangle frame
+// 90.7 -> 89.9 ms, 10M-triangle 1588 -> 1565) and 1-3 % slower in the Whitted kernel (64-sphere frame
+// 17.5 -> 17.9 ms, photon frame 970 -> 979), so it stays a switch.  The kd-tree walk's stack (photon.h)
+// is typed: its pops would otherwise wait for the lookup's global stores.
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #ifdef RT_STACK_TYPED
 typedef __attribute__((address_space(3))) u32x2 *LdsStackPtr;
