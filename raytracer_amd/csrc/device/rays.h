@@ -283,7 +283,7 @@ template <bool COUNT, int LEVELS, class IO> struct RayWalker {
             if (cur == kNoNode && sp > 0) {
                 --sp;
                 uint32_t data; float nodeT;
-                st.pop(sp, data, nodeT);
+                st.pop_named(sp, data, nodeT);
                 if (!(t_limit < nodeT)) cur = data; // else: entered farther than the best hit so far
             }
             if (cur != kNoNode) {
@@ -315,9 +315,9 @@ template <bool COUNT, int LEVELS, class IO> struct RayWalker {
                     };
                     order(d0, k0, d1, k1); order(d2, k2, d3, k3); order(d0, k0, d2, k2); order(d1, k1, d3, k3); order(d1, k1, d2, k2);
                     // farthest first onto the stack, the nearest is visited next
-                    if (d3 < INFINITY) { st.push(sp, k3, d3); ++sp; }
-                    if (d2 < INFINITY) { st.push(sp, k2, d2); ++sp; }
-                    if (d1 < INFINITY) { st.push(sp, k1, d1); ++sp; }
+                    if (d3 < INFINITY) { st.push_named(sp, k3, d3); ++sp; }
+                    if (d2 < INFINITY) { st.push_named(sp, k2, d2); ++sp; }
+                    if (d1 < INFINITY) { st.push_named(sp, k1, d1); ++sp; }
                     cur = d0 < INFINITY ? k0 : kNoNode;
                 } else {
                     const uint32_t c1 = cur & 0x7FFFFFFFu;
@@ -330,7 +330,7 @@ template <bool COUNT, int LEVELS, class IO> struct RayWalker {
                     h2 = h2 && d2 < t_limit;
                     const uint32_t k1 = __float_as_uint(a1.z), k2 = __float_as_uint(b1.z);
                     const bool firstNear = d1 < d2; // on a tie the second child is visited first
-                    if (h1 && h2) { st.push(sp, firstNear ? k2 : k1, firstNear ? d2 : d1); ++sp; }
+                    if (h1 && h2) { st.push_named(sp, firstNear ? k2 : k1, firstNear ? d2 : d1); ++sp; }
                     cur = h1 ? ((h2 && !firstNear) ? k2 : k1) : (h2 ? k2 : kNoNode);
                 }
             }

@@ -39,8 +39,9 @@ constexpr uint32_t kStackStride = 256;
 // (RT_STACK_TYPED: ds_read/ds_write for the LDS levels, global_load/store for the overflow) looks like
 // the obvious thing to do; measured, it is 1 % faster in the path tracer's kernels (1M-triangle frame
 // 90.7 -> 89.9 ms, 10M-triangle 1588 -> 1565) and 1-3 % slower in the Whitted kernel (64-sphere frame
-// 17.5 -> 17.9 ms, photon frame 970 -> 979), so it stays a switch.  The kd-tree walk's stack (photon.h)
-// is typed: its pops would otherwise wait for the lookup's global stores.
+// 17.5 -> 17.9 ms, photon frame 970 -> 979), so it stays a switch - and the ray-list walker, where the
+// gain is, names the spaces itself (push_named / pop_named below).  The kd-tree walk's stack (photon.h)
+// is typed too: its pops would otherwise wait for the lookup's global stores.
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #ifdef RT_STACK_TYPED
 typedef __attribute__((address_space(3))) u32x2 *LdsStackPtr;
@@ -65,6 +66,22 @@ struct LaneStack {
         u32x2 e;
         if ((uint32_t)sp < lds_levels) e = lds[(uint32_t)sp * kStackStride];
         else e = ovf[(size_t)((uint32_t)sp - lds_levels) * ovf_stride];
+        data = e.x; dist = __uint_as_float(e.y);
+    }
+    // the same with the address spaces named, whatever the switch says: the ray-list walker (rays.h) gains by it
+    typedef __attribute__((address_space(3))) u32x2 *NamedLds;
+    typedef __attribute__((address_space(1))) u32x2 *NamedGlobal;
+    RT_DEV void push_named(int sp, uint32_t data, float dist) const
+    {
+        const u32x2 e = {data, __float_as_uint(dist)};
+        if ((uint32_t)sp < lds_levels) ((NamedLds)lds)[(uint32_t)sp * kStackStride] = e;
+        else ((NamedGlobal)ovf)[(size_t)((uint32_t)sp - lds_levels) * ovf_stride] = e;
+    }
+    RT_DEV void pop_named(int sp, uint32_t &data, float &dist) const
+    {
+        u32x2 e;
+        if ((uint32_t)sp < lds_levels) e = ((NamedLds)lds)[(uint32_t)sp * kStackStride];
+        else e = ((NamedGlobal)ovf)[(size_t)((uint32_t)sp - lds_levels) * ovf_stride];
         data = e.x; dist = __uint_as_float(e.y);
     }
 };
