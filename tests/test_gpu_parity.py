@@ -81,6 +81,27 @@ def test_ray_list_kernel_vs_reference(ctx, name):
         ctx.trace_brief(rays[:4], np.array([1.0, -1.0, 2.0, 3.0], np.float32))
 
 
+@pytest.mark.parametrize("name", ["kat_trace_a", "kat_trace_mesh"])
+def test_ray_list_lengths_vs_reference(ctx, name):
+    """Ragged list lengths around the portions the waves take from the list (64 .. 1024 rays, chosen from the length):
+    every prefix must give the reference's answers, closest hits and shadow rays."""
+    g = O.load_golden(name)
+    s = O.scene_from_golden(g)
+    ctx.upload(s.desc)
+    reps = 40
+    rays = np.tile(g["kat_rays"], (reps, 1))
+    ref_id, ref_z = np.tile(g["kat_id"], reps), np.tile(g["kat_hit"][:, 0], reps)
+    tmax, ref_occ = np.tile(g["kat_tmax"], reps), np.tile(g["kat_flags"][:, 2], reps)
+    for n in (1, 2, 63, 64, 65, 127, 129, 1000, 4097, 65537, len(rays)):
+        n = min(n, len(rays))
+        got = ctx.trace_brief(rays[:n])
+        assert np.array_equal(got["node"], ref_id[:n]), f"hit node ids of {n} rays"
+        assert np.array_equal(bits(got["t"]), bits(ref_z[:n])), f"z of {n} rays"
+        occ = ctx.trace_brief(rays[:n], tmax[:n])
+        assert np.array_equal(occ["node"], ref_occ[:n]), f"shadow rays, {n} of them"
+    assert len(ctx.trace_brief(rays[:0])["node"]) == 0
+
+
 def test_path_radiance_vs_reference(ctx):
     g = O.load_golden("kat_paths_a")
     s = O.scene_from_golden(g)
