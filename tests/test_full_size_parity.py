@@ -270,6 +270,30 @@ def test_photon_maps_vs_reference(ctx, name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("radius", [0.02, 0.6, 3.0, 50.0])
+def test_photon_lookup_radii_vs_oracle(ctx, radius):
+    """The irradiance estimate at hundreds of query points for radii from "finds nothing" over "fewer than 128 photons" to
+    "the array fills early and most photons replace one" (the register / LDS / global-memory levels of the heap, entry
+    128, the heap's construction): bit for bit the oracle's, whose estimates the reference's own fixtures pin."""
+    g = O.load_golden("photons_a_large")
+    s = O.scene_from_golden(g)
+    ctx.upload(s.desc)
+    tree = g["pm_global_tree"].view(abi.PHOTON_DTYPE).reshape(-1)
+    ctx.photons_build(abi.RT_MAP_GLOBAL, g["pm_global_raw"].view(abi.PHOTON_DTYPE).reshape(-1))
+    rng = np.random.RandomState(int(radius * 100))
+    # query points next to photons, normals in every direction (about half of the photons pass the direction test)
+    pick = rng.randint(0, len(tree), 600)
+    pos = tree["pos"][pick] + rng.normal(0, 0.05, (600, 3)).astype(np.float32)
+    nrm = rng.normal(0, 1, (600, 3)).astype(np.float32)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    e = ctx.photons_irradiance(abi.RT_MAP_GLOBAL, pos, nrm, radius)
+    ref = O.photon_irradiance(tree, pos, nrm, radius)
+    assert np.array_equal(bits(e), bits(ref)), f"radius {radius}: {np.sum(np.any(bits(e) != bits(ref), axis=1))} of 600 estimates differ"
+    if radius >= 3.0:
+        assert (e.sum(axis=1) > 0).mean() > 0.5
+
+
+@pytest.mark.gpu
 def test_whitted_photon_image_with_this_context(ctx):
     g = O.load_golden("whitted_pm_a_64x36_b5")
     s = O.scene_from_golden(g)
