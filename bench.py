@@ -11,7 +11,10 @@ planes; the timed region ends when the last copy has).
 A ray is one TraceRay or TraceShadowRay call equivalent of the reference
 (src/main.cpp:115-125); rays are counted by the kernels, not estimated.
 
-For N > 1 launch through torch.distributed.run (one process per GPU).
+For N > 1 there is one process per GPU: started by torch.distributed.run (RANK / WORLD_SIZE in the
+environment), or, when the script is started bare (`python bench.py --gpus 8`), by the script itself, which
+then starts its ranks through torch.distributed.run as a child process before anything has touched a GPU and
+relays rank 0's line (the reference starts its own workers too: src/main.cpp:599-606).
 """
 import argparse
 import json
@@ -206,20 +209,38 @@ def main():
                     help="development only: one GPU renders the tiles rank R of W would get (no gather): per-rank time of a W-GPU run")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started bare: this process (which has not touched a GPU: importing torch does not) starts one rank per GPU
+        # as a child and hands on its exit code; the ranks inherit stdout, so rank 0's JSON line appears as usual
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     if world != args.gpus:
-        sys.exit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        sys.exit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the two must agree")
+    # RT_BENCH_REHEARSE=1: every rank on GPU 0, records exchanged over gloo through host memory - the N > 1 code path
+    # (launch, sharding, pack, all-gather, unpack, reductions) on a box with one GPU.  Its line says so; not a measurement.
+    rehearsal = os.environ.get("RT_BENCH_REHEARSE") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    # RT_BENCH_GROUP=1 takes the N > 1 code path (process group, frame exchange, reductions) with a single rank: a
-    # rehearsal of the multi-GPU path on a one-GPU box
+    # RT_BENCH_GROUP=1 takes the N > 1 code path (process group, frame exchange, reductions) with a single rank
     grouped = world > 1 or os.environ.get("RT_BENCH_GROUP") == "1"
     if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     hs, w, h, (spp_min, spp_max), ntri, mode, bounces, pp = build_scene(args.workload)
     if args.max_bounces is not None:
@@ -238,8 +259,8 @@ def main():
     # runs while the library, on its own stream, renders the next frame into the other set
     fbs = [FrameBuffers(w, h, dev), FrameBuffers(w, h, dev)]
     fb = fbs[0]
-    gather = FrameGather(w, h, prm.tile_size, rank, world, dev, ctx=ctx, exchange=grouped)
-    filler = PhotonFill(ctx, rank, world, dev) if pp else None
+    gather = FrameGather(w, h, prm.tile_size, rank, world, dev, ctx=ctx, exchange=grouped, via_host=rehearsal)
+    filler = PhotonFill(ctx, rank, world, dev, via_host=rehearsal) if pp else None
     host_rgbs = [torch.empty((w * h, 3), dtype=torch.uint8).pin_memory() for _ in fbs]
     copied = [torch.cuda.Event() for _ in fbs]
     photon_stats = {}
@@ -296,8 +317,8 @@ def main():
     c = ctx.counters()
     photon_rays = photon_stats.get("rays", 0)
     stats = torch.tensor([c.closest_rays, c.shadow_rays, c.camera_paths, counted.box_tests, counted.tri_tests,
-                          c.gathers, counted.photon_visits, photon_rays], dtype=torch.float64, device=dev)
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+                          c.gathers, counted.photon_visits, photon_rays], dtype=torch.float64, device="cpu" if rehearsal else dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else dev)
     if grouped:
         dist.all_reduce(stats)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -331,7 +352,7 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" if not rehearsal else "synthetic; REHEARSAL: all ranks share GPU 0 and exchange over gloo - not a measurement",
             "config": {"workload": args.workload, "triangles": ntri, "width": w, "height": h, "spp": [spp_min, spp_max],
                        "max_bounces": prm.max_bounces, "mode": "path" if mode == abi.RT_MODE_PATH else "whitted",
                        "parallelism": f"tiles/{world}", "rays_per_frame": int(rays_per_frame),

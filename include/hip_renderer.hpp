@@ -22,6 +22,7 @@
 #include "rt_mi355x.h"
 
 #include <atomic>
+#include <chrono>
 #include <cfloat>
 #include <cstdint>
 #include <cstdio>
@@ -120,6 +121,7 @@ class HipRenderer {
     RenderImage renderImage;
     std::string sceneFile;
     std::atomic<bool> isRendering{false};
+    std::atomic<bool> stopRequested{false}; // StopRender has been called for the frame the worker was started for
     std::thread worker;
     mutable std::mutex gpu; // one call at a time on the context (rt_cancel and rt_progress excepted)
     rt_render_params params{};
@@ -197,6 +199,7 @@ public:
     {
         if (!ctx || !host) return Fail("RenderFrame", "no scene loaded");
         std::lock_guard<std::mutex> lock(gpu);
+        if (stopRequested) { lastStatus = RT_ERR_CANCELLED; return false; } // stopped before the frame began
         renderImage.ResetNumRenderedPixels();
         rt_frame_out out{};
         out.rgb = (uint8_t *)renderImage.GetPixels();
@@ -227,6 +230,7 @@ public:
     void BeginRender()
     {
         StopRender();
+        stopRequested = false;
         isRendering = true;
         worker = std::thread([this] { RenderFrame(); isRendering = false; });
     }
@@ -234,7 +238,14 @@ public:
     void StopRender()
     {
         if (worker.joinable()) {
-            if (isRendering && ctx) rt_cancel(ctx); // no new work for the GPU: the worker returns within milliseconds
+            // rt_render clears the flag of an earlier call when it starts, so a request that arrives while the worker
+            // is still on its way into rt_render would be lost: the worker looks at stopRequested before it calls, and
+            // the request is repeated until the worker is out (no new work for the GPU: it returns within milliseconds)
+            stopRequested = true;
+            while (isRendering && ctx) {
+                rt_cancel(ctx);
+                std::this_thread::sleep_for(std::chrono::microseconds(200));
+            }
             worker.join();
         }
         isRendering = false;

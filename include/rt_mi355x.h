@@ -306,14 +306,19 @@ typedef struct rt_hit_brief {
 } rt_hit_brief;
 int rt_trace_brief(rt_ctx *ctx, const float *rays6, const float *t_max, int n, rt_hit_brief *out);
 
-/* rt_trace_brief for callers that cannot allocate device memory (code under HIP graph capture, tight serving
- * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  All three arrays are DEVICE memory
- * (t_max may be null; its entries must be >= 0); the answers are those of rt_trace_brief, bit for bit.  The call
+/* rt_trace_brief for callers that cannot allocate device memory (tight serving loops, harnesses that forbid
+ * hipMalloc, code that runs between the capture and the replay of HIP graphs).  No counterpart in the reference.
+ * All three arrays are DEVICE memory (t_max may be null); the answers are those of rt_trace_brief, bit for bit.
+ * A negative t_max entry lets nothing occlude its ray (the walk compares t < t_max): the answer is "not
+ * occluded"; the answer for a NaN entry is undefined.  rt_trace_brief refuses both on the host; this call cannot
+ * look at device memory there.  The call
  * makes no hipMalloc / hipFree: the kernel's work queue, counters and the BVH-stack levels beyond LDS live in a
  * static 32 MiB device array of the library, one per GPU, shared by every context and call on that GPU - calls
  * that overlap in time on one GPU race.  At most RT_NOALLOC_MAX_RAYS rays per call (RT_ERR_INVALID beyond);
- * RT_ERR_UNSUPPORTED if the scene's BVH needs more stack than the array holds for one workgroup.  Returns after
- * the answers are complete (synchronises the context's stream); only kernel_ms of rt_get_counters is updated. */
+ * RT_ERR_UNSUPPORTED if the scene's BVH needs more stack than the array holds for one workgroup.  It enqueues a
+ * memset and a kernel on the context's own stream and returns after the answers are complete (it synchronises
+ * that stream, so it cannot itself be called while a stream is being captured); only kernel_ms of
+ * rt_get_counters is updated. */
 #define RT_NOALLOC_MAX_RAYS (1 << 24)
 int rt_trace_brief_noalloc(rt_ctx *ctx, const float *d_rays6, const float *d_t_max, int n, rt_hit_brief *d_out);
 

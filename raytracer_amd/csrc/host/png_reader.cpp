@@ -73,25 +73,26 @@ const uint8_t kLenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3
 const uint16_t kDistBase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
 const uint8_t kDistExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
 
-bool inflate_block(Bits &b, const Code &lit, const Code &dist, std::vector<uint8_t> &out)
+// `limit`: the most the stream may expand to (a small file can expand a thousandfold: the caller knows what it expects)
+bool inflate_block(Bits &b, const Code &lit, const Code &dist, std::vector<uint8_t> &out, size_t limit)
 {
     for (;;) {
         const int s = lit.decode(b);
         if (s < 0) return false;
-        if (s < 256) { out.push_back((uint8_t)s); continue; }
+        if (s < 256) { if (out.size() >= limit) return false; out.push_back((uint8_t)s); continue; }
         if (s == 256) return true;
         if (s > 285) return false;
         const size_t len = kLenBase[s - 257] + b.take(kLenExtra[s - 257]);
         const int ds = dist.decode(b);
         if (ds < 0 || ds > 29) return false;
         const size_t back = kDistBase[ds] + b.take(kDistExtra[ds]);
-        if (b.overrun || back > out.size()) return false;
+        if (b.overrun || back > out.size() || len > limit - out.size()) return false;
         const size_t from = out.size() - back;
         for (size_t i = 0; i < len; ++i) out.push_back(out[from + i]); // may overlap what it writes
     }
 }
 
-bool inflate(Bits &b, std::vector<uint8_t> &out)
+bool inflate(Bits &b, std::vector<uint8_t> &out, size_t limit)
 {
     for (;;) {
         const uint32_t last = b.take(1), type = b.take(2);
@@ -101,7 +102,7 @@ bool inflate(Bits &b, std::vector<uint8_t> &out)
             if (b.pos + 4 > b.n) return false;
             const uint32_t len = b.p[b.pos] | (b.p[b.pos + 1] << 8), nlen = b.p[b.pos + 2] | (b.p[b.pos + 3] << 8);
             b.pos += 4;
-            if ((len ^ 0xFFFFu) != nlen || b.pos + len > b.n) return false;
+            if ((len ^ 0xFFFFu) != nlen || b.pos + len > b.n || len > limit - out.size()) return false;
             out.insert(out.end(), b.p + b.pos, b.p + b.pos + len);
             b.pos += len;
         } else if (type == 1) {
@@ -114,7 +115,7 @@ bool inflate(Bits &b, std::vector<uint8_t> &out)
             Code lit, dist;
             lit.build(l, 288);
             dist.build(l + 288, 30);
-            if (!inflate_block(b, lit, dist, out)) return false;
+            if (!inflate_block(b, lit, dist, out, limit)) return false;
         } else if (type == 2) {
             const int nlit = (int)b.take(5) + 257, ndist = (int)b.take(5) + 1, ncode = (int)b.take(4) + 4;
             if (b.overrun || nlit > 286 || ndist > 30) return false;
@@ -141,7 +142,7 @@ bool inflate(Bits &b, std::vector<uint8_t> &out)
             Code lit, dist;
             if (!lit.build(l, nlit)) return false;
             if (!dist.build(l + nlit, ndist)) return false;
-            if (!inflate_block(b, lit, dist, out)) return false;
+            if (!inflate_block(b, lit, dist, out, limit)) return false;
         } else return false;
         if (last) return !b.overrun;
     }
@@ -149,18 +150,22 @@ bool inflate(Bits &b, std::vector<uint8_t> &out)
 
 uint32_t be32(const uint8_t *p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
 
-uint32_t crc32(const uint8_t *p, size_t n)
-{
-    static uint32_t table[256];
-    static bool ready = false;
-    if (!ready) {
+struct CrcTable {
+    uint32_t v[256];
+    CrcTable()
+    {
         for (uint32_t i = 0; i < 256; ++i) {
             uint32_t c = i;
             for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
-            table[i] = c;
+            v[i] = c;
         }
-        ready = true;
     }
+};
+
+uint32_t crc32(const uint8_t *p, size_t n)
+{
+    static const CrcTable built; // initialised once, thread-safe (a function-local static)
+    const uint32_t *table = built.v;
     uint32_t c = 0xFFFFFFFFu;
     for (size_t i = 0; i < n; ++i) c = table[(c ^ p[i]) & 0xFFu] ^ (c >> 8);
     return c ^ 0xFFFFFFFFu;
@@ -224,13 +229,13 @@ void pixel_rgb(const Header &H, const uint8_t *row, size_t x, const uint8_t *pal
 
 } // namespace
 
-bool zlib_inflate(const uint8_t *src, size_t n, std::vector<uint8_t> &out, std::string &err)
+bool zlib_inflate(const uint8_t *src, size_t n, std::vector<uint8_t> &out, std::string &err, size_t limit)
 {
     if (n < 6) { err = "zlib stream too short"; return false; }
     if ((src[0] & 0x0F) != 8 || ((src[0] << 8) | src[1]) % 31 != 0 || (src[1] & 0x20)) { err = "bad zlib header"; return false; }
     Bits b{src + 2, n - 2};
     out.clear();
-    if (!inflate(b, out)) { err = "corrupt deflate data"; return false; }
+    if (!inflate(b, out, limit)) { err = out.size() >= limit ? "deflate data expands beyond what the image needs" : "corrupt deflate data"; return false; }
     b.to_byte();
     if (b.pos + 4 > b.n) { err = "zlib stream ends before its checksum"; return false; }
     uint32_t s1 = 1, s2 = 0;
@@ -278,15 +283,23 @@ bool decode_png_rgb8(const uint8_t *file, size_t size, int &width, int &height, 
         pos += 12 + (size_t)len;
     }
     if (H.ctype == 3 && palette.empty()) { err = "palette PNG without a palette"; return false; }
-    std::vector<uint8_t> raw;
-    if (!zlib_inflate(idat.data(), idat.size(), raw, err)) return false;
-
     const size_t bits = (size_t)channels_of(H.ctype) * H.depth;
     const size_t bpp = bits >= 8 ? bits / 8 : 1;
-    width = (int)H.w; height = (int)H.h;
-    rgb.assign((size_t)H.w * H.h * 3, 0);
     // the passes of the image: one for a plain file, seven reduced images for an interlaced one (Adam7)
     static const uint32_t x0[7] = {0, 4, 0, 2, 0, 1, 0}, y0[7] = {0, 0, 4, 0, 2, 0, 1}, dx[7] = {8, 8, 4, 4, 2, 2, 1}, dy[7] = {8, 8, 8, 4, 4, 2, 2};
+    // what the scanlines of all passes take, filter bytes included: the stream may not expand beyond it
+    size_t expected = 0;
+    for (int pass = 0; pass < (H.interlace ? 7 : 1); ++pass) {
+        const uint32_t sx = H.interlace ? x0[pass] : 0, sy = H.interlace ? y0[pass] : 0, px = H.interlace ? dx[pass] : 1, py = H.interlace ? dy[pass] : 1;
+        const size_t pw = H.w > sx ? (H.w - sx + px - 1) / px : 0, ph = H.h > sy ? (H.h - sy + py - 1) / py : 0;
+        if (pw && ph) expected += ph * ((pw * bits + 7) / 8 + 1);
+    }
+    std::vector<uint8_t> raw;
+    raw.reserve(expected);
+    if (!zlib_inflate(idat.data(), idat.size(), raw, err, expected)) return false;
+
+    width = (int)H.w; height = (int)H.h;
+    rgb.assign((size_t)H.w * H.h * 3, 0);
     size_t at = 0;
     std::vector<uint8_t> rows;
     for (int pass = 0; pass < (H.interlace ? 7 : 1); ++pass) {

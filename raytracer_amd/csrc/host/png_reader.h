@@ -13,7 +13,7 @@ namespace rt {
 bool decode_png_rgb8(const uint8_t *file, size_t size, int &width, int &height, std::vector<uint8_t> &rgb, std::string &err);
 bool load_png_rgb8(const std::string &path, int &width, int &height, std::vector<uint8_t> &rgb, std::string &err);
 
-// RFC 1950 / 1951: a zlib stream (header, deflate blocks, Adler-32) -> bytes
-bool zlib_inflate(const uint8_t *src, size_t n, std::vector<uint8_t> &out, std::string &err);
+// RFC 1950 / 1951: a zlib stream (header, deflate blocks, Adler-32) -> bytes; fails once the output would pass `limit`
+bool zlib_inflate(const uint8_t *src, size_t n, std::vector<uint8_t> &out, std::string &err, size_t limit = (size_t)-1);
 
 } // namespace rt

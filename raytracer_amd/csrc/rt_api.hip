@@ -110,6 +110,7 @@ struct rt_ctx {
     // [1] how far the running lock-step kernel's queue has been handed out
     unsigned long long *host_words = nullptr;
     std::atomic<int> cancel_req{0};
+    int cancellable_depth = 0; // > 0 inside rt_photons_fill: the rt_photons_emit calls it makes belong to its cancellable call
     std::atomic<uint64_t> prog_pixels_total{0}, prog_pixels_done{0}, prog_round_items{0}, prog_round_done{0};
     std::atomic<int> prog_round{0}, prog_rendering{0}, prog_live_queue{0}; // live_queue: the round's progress is the queue word of the running kernel
 
@@ -1101,6 +1102,27 @@ int rt_render(rt_ctx *ctx, const rt_render_params *prm, rt_frame_out *out)
         if (out->linear) { HIP_TRY(ctx, ctx->d_lin.reserve(npx * 12)); P.linear = ctx->d_lin.as<float>(); }
     }
 
+    // the caller's host planes, from the internal ones (also on a cancelled frame: the pixels finished so far are in them)
+    const auto planes_to_host = [&]() -> int {
+        if (dev_out) return RT_OK;
+        // whole image: straight copies; a tile shard: stage and copy only the rows of its tiles
+        const bool whole = prm->tile_world == 1;
+        struct Plane { void *dst; const DeviceBuf *src; size_t px_bytes; };
+        const Plane planes[5] = {{out->rgb, &ctx->d_rgb, 3}, {out->z, &ctx->d_z, 4}, {out->sample_count, &ctx->d_cnt, 4},
+                                 {out->object_id, &ctx->d_id, 4}, {out->linear, &ctx->d_lin, 12}};
+        std::vector<uint8_t> stage;
+        for (const Plane &pl : planes) {
+            if (!pl.dst) continue;
+            if (whole) { HIP_TRY(ctx, hipMemcpyAsync(pl.dst, pl.src->p, npx * pl.px_bytes, hipMemcpyDeviceToHost, s)); continue; }
+            stage.resize(npx * pl.px_bytes);
+            HIP_TRY(ctx, hipMemcpyAsync(stage.data(), pl.src->p, npx * pl.px_bytes, hipMemcpyDeviceToHost, s));
+            HIP_TRY(ctx, hipStreamSynchronize(s));
+            for (int32_t pix : ctx->active_host)
+                memcpy((uint8_t *)pl.dst + (size_t)pix * pl.px_bytes, stage.data() + (size_t)pix * pl.px_bytes, pl.px_bytes);
+        }
+        return hipStreamSynchronize(s) == hipSuccess ? RT_OK : ctx->fail(RT_ERR_HIP, "copy of the frame to the host failed");
+    };
+
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters.p, 0, sizeof(DCounters), s));
 #ifdef RT_PROFILE_TAIL
     HIP_TRY(ctx, hipMemsetAsync((char *)ctx->d_counters.p + offsetof(DCounters, phase) + 12 * 8, 0xFF, 8, s)); // the minimum starts at the top
@@ -1253,7 +1275,10 @@ int rt_render(rt_ctx *ctx, const rt_render_params *prm, rt_frame_out *out)
         HIP_TRY(ctx, hipMemcpyAsync(&next, ctx->d_next_count.p, sizeof next, hipMemcpyDeviceToHost, s));
         HIP_TRY(ctx, hipStreamSynchronize(s));
         ctx->prog_live_queue.store(0);
-        if (cancelled(ctx)) return ctx->fail(RT_ERR_CANCELLED, "cancelled by rt_cancel after %d samples per pixel", k0);
+        if (cancelled(ctx)) {
+            if (int rc = planes_to_host()) return rc;
+            return ctx->fail(RT_ERR_CANCELLED, "cancelled by rt_cancel after %d samples per pixel", k0);
+        }
         ctx->prog_pixels_done.store(n0 - next);
         n_active = next;
         cur ^= 1;
@@ -1263,23 +1288,7 @@ int rt_render(rt_ctx *ctx, const rt_render_params *prm, rt_frame_out *out)
 
     DCounters dc{};
     HIP_TRY(ctx, hipMemcpyAsync(&dc, ctx->d_counters.p, sizeof dc, hipMemcpyDeviceToHost, s));
-    if (!dev_out) {
-        // whole image: straight copies; a tile shard: stage and copy only the rows of its tiles
-        const bool whole = prm->tile_world == 1;
-        struct Plane { void *dst; const DeviceBuf *src; size_t px_bytes; };
-        const Plane planes[5] = {{out->rgb, &ctx->d_rgb, 3}, {out->z, &ctx->d_z, 4}, {out->sample_count, &ctx->d_cnt, 4},
-                                 {out->object_id, &ctx->d_id, 4}, {out->linear, &ctx->d_lin, 12}};
-        std::vector<uint8_t> stage;
-        for (const Plane &pl : planes) {
-            if (!pl.dst) continue;
-            if (whole) { HIP_TRY(ctx, hipMemcpyAsync(pl.dst, pl.src->p, npx * pl.px_bytes, hipMemcpyDeviceToHost, s)); continue; }
-            stage.resize(npx * pl.px_bytes);
-            HIP_TRY(ctx, hipMemcpyAsync(stage.data(), pl.src->p, npx * pl.px_bytes, hipMemcpyDeviceToHost, s));
-            HIP_TRY(ctx, hipStreamSynchronize(s));
-            for (int32_t pix : ctx->active_host)
-                memcpy((uint8_t *)pl.dst + (size_t)pix * pl.px_bytes, stage.data() + (size_t)pix * pl.px_bytes, pl.px_bytes);
-        }
-    }
+    if (int rc = planes_to_host()) return rc;
     HIP_TRY(ctx, hipStreamSynchronize(s));
     float ms = 0;
     HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
@@ -1642,6 +1651,9 @@ int rt_photons_emit(rt_ctx *ctx, const rt_photon_params *pp, int which, uint64_t
     hipStream_t s = ctx->stream;
     *n_stored = 0;
     if (!map_enabled(pp->flags, which) || path_count == 0) return RT_OK;
+    // a call of its own starts with a clear flag (a request left over from an earlier call, or made while nothing ran,
+    // would make the kernels' work queues hand out nothing); inside rt_photons_fill the flag is that call's
+    if (ctx->cancellable_depth == 0) if (int rc = begin_cancellable(ctx)) return rc;
     rt_photon *d_out = out;
     if (!device_memory) {
         HIP_TRY(ctx, ctx->d_ph_raw.reserve(std::max<size_t>(1, capacity) * sizeof(rt_photon)));
@@ -1664,6 +1676,7 @@ int rt_photons_emit(rt_ctx *ctx, const rt_photon_params *pp, int which, uint64_t
     DCounters dc{};
     HIP_TRY(ctx, hipMemcpyAsync(&dc, ctx->d_counters.p, sizeof dc, hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));
+    if (cancelled(ctx)) return ctx->fail(RT_ERR_CANCELLED, "cancelled by rt_cancel while tracing photon paths"); // the counts are those of a stopped queue
     *n_stored = stored;
     float ms = 0;
     HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->evk0, ctx->evk1));
@@ -1770,6 +1783,7 @@ int rt_photons_fill(rt_ctx *ctx, const rt_photon_params *pp)
     if (int rc = validate_photon_params(ctx, pp, RT_MAP_GLOBAL)) return rc;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (int rc = begin_cancellable(ctx)) return rc;
+    struct Nest { rt_ctx *c; Nest(rt_ctx *x) : c(x) { ++c->cancellable_depth; } ~Nest() { --c->cancellable_depth; } } nest(ctx);
     double emit_ms = 0.0;
     uint64_t rays = 0, paths_total = 0;
     for (int which = 0; which < 2; ++which) {

@@ -50,6 +50,17 @@ def record_pixels(width, height, tile_size, rank, world):
     return s[ok], (y * width + x)[ok]
 
 
+def all_gather_flat(recv, send, via_host=False):
+    """all_gather_into_tensor of flat views; via_host stages both sides through host memory (a gloo group whose
+    ranks keep their tensors on a GPU: the rehearsal of the multi-GPU path on one GPU)."""
+    if not via_host or not send.is_cuda:
+        dist.all_gather_into_tensor(recv.view(-1), send.view(-1))
+        return
+    r = torch.empty(recv.numel(), dtype=recv.dtype)
+    dist.all_gather_into_tensor(r, send.reshape(-1).cpu())
+    recv.view(-1).copy_(r)
+
+
 class FrameBuffers:
     """Full-frame planes in the memory of `device` (torch tensors; the library writes through data_ptr())."""
 
@@ -72,8 +83,8 @@ class FrameGather:
     pixel in the exchange array is arithmetic, no index lists); without one (the CPU tests of the N > 1 path) the same
     record layout is produced with torch indexing."""
 
-    def __init__(self, width, height, tile_size, rank, world, device, ctx=None, exchange=None):
-        self.world, self.rank, self.ctx, self.tile = world, rank, ctx, tile_size
+    def __init__(self, width, height, tile_size, rank, world, device, ctx=None, exchange=None, via_host=False):
+        self.world, self.rank, self.ctx, self.tile, self.via_host = world, rank, ctx, tile_size, via_host
         self.n = frame_records(width, height, tile_size, world)
         # a single rank has nothing to exchange; exchange=True makes it go through pack / all_gather / unpack all the same
         self.exchange = world > 1 if exchange is None else bool(exchange)
@@ -119,7 +130,7 @@ class FrameGather:
         if not self.exchange:
             return fb
         self.pack(fb)  # on the library's stream, finished when it returns
-        dist.all_gather_into_tensor(self.recv.view(-1), self.send.view(-1))
+        all_gather_flat(self.recv, self.send, self.via_host)
         if self.ctx is not None:
             torch.cuda.current_stream().synchronize()  # the unpack kernel runs on the library's stream
         self.unpack(fb)
@@ -143,8 +154,8 @@ class PhotonFill:
 
     FIRST_ROUND = 1 << 16
 
-    def __init__(self, ctx, rank, world, device, emit=None, build=None):
-        self.ctx, self.rank, self.world, self.device = ctx, rank, world, device
+    def __init__(self, ctx, rank, world, device, emit=None, build=None, via_host=False):
+        self.ctx, self.rank, self.world, self.device, self.via_host = ctx, rank, world, device, via_host
         self.emit = emit or self._emit_gpu
         self.build = build or self._build_gpu
         self._scratch = None
@@ -184,13 +195,13 @@ class PhotonFill:
                 if world > 1:
                     counts = torch.zeros(world, dtype=torch.int64, device=self.device)
                     me = torch.tensor([n_mine], dtype=torch.int64, device=self.device)
-                    dist.all_gather_into_tensor(counts, me)
+                    all_gather_flat(counts, me, self.via_host)
                     counts = counts.tolist()
                     most = max(1, max(counts))
                     send = torch.zeros((most, 32), dtype=torch.uint8, device=self.device)
                     send[:n_mine] = mine[:n_mine]
                     recv = torch.empty((world, most, 32), dtype=torch.uint8, device=self.device)
-                    dist.all_gather_into_tensor(recv.view(-1), send.view(-1))
+                    all_gather_flat(recv, send, self.via_host)
                     parts = [recv[r, :counts[r]] for r in range(world)]
                 else:
                     counts, parts = [n_mine], [mine[:n_mine]]

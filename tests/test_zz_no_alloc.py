@@ -23,7 +23,9 @@ def run_noalloc(ctx, rays, tmax):
     d_tmax = torch.from_numpy(np.ascontiguousarray(tmax, np.float32)).cuda() if tmax is not None else None
     d_out = torch.full((len(rays), abi.HIT_BRIEF_DTYPE.itemsize), 0xAB, dtype=torch.uint8, device="cuda")
     torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info()[0]
     ctx.trace_brief_noalloc(d_rays.data_ptr(), d_tmax.data_ptr() if d_tmax is not None else 0, len(rays), d_out.data_ptr())
+    assert torch.cuda.mem_get_info()[0] == free_before, "the call changed the device's free memory: it allocated"
     return d_out.cpu().numpy().view(abi.HIT_BRIEF_DTYPE).reshape(-1)
 
 
