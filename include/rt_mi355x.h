@@ -239,7 +239,7 @@ typedef struct rt_counters {
     double kernel_ms;       /* GPU time of the last rt_render, HIP events on the render stream */
     double trace_kernel_ms; /* of which: the dominant kernel's launches (k_paths / k_whitted; the ray-list kernel k_rays in the wavefront pipeline) */
     uint32_t trace_launches; /* how many such launches */
-    uint32_t trace_pipeline; /* 0 = lock-step kernel (one launch per sampling round), 1 = wavefront pipeline (one k_rays launch per bounce) */
+    uint32_t trace_pipeline; /* after rt_render: 0 = lock-step kernel (one launch per sampling round), 1 = wavefront pipeline (one k_rays launch per bounce); after rt_trace_brief: 0 = the reference's binary BVH walk, 2 = the four-wide walk of the frames' rays (RT_QUERY_WIDE=1 in the environment at rt_init: a test gate) */
     uint64_t phase_cycles[16]; /* diagnostic builds only (RT_PROFILE_PHASES): per kernel phase wave clocks [0..3], executions [4..7], active lanes [8..11] */
     double bvh_build_ms;    /* GPU time the last rt_scene_upload spent building BVHs (0: the scene brought them) */
 } rt_counters;

@@ -15,6 +15,7 @@ reference source text.
     python oracle/make_golden.py --photons-large  # only the tall photon map
     python oracle/make_golden.py --png            # only the PNG decoding cases
     python oracle/make_golden.py --multimtl       # only the OBJ-with-materials scene
+    python oracle/make_golden.py --lights         # only the scene with ambient + directional + spherical light
 """
 import os
 import subprocess
@@ -86,6 +87,17 @@ def whitted():
         p = os.path.join(tmp, "mesh.xml")
         open(p, "w").write(xml)
         image("whitted_mesh_96x54_b5", p, scene_bundle(p, cwd=tmp, harness=H), 7, 4, 4, 0.01, 96, 54, 5, cwd=tmp)
+        lights(tmp, image)
+
+
+def lights(tmp, image):
+    """Ambient + directional + spherical light in one scene, through the snapshot's shader (its light loop,
+    AmbientLight / DirectLight::Illuminate) with reflection and refraction on."""
+    xml = scenes.lights_scene_xml(width=96, height=54)
+    p = os.path.join(tmp, "lights.xml")
+    open(p, "w").write(xml)
+    image("whitted_lights_96x54_b5", p, scene_bundle(p, harness=HARNESS_P12), 7, 4, 4, 0.01, 96, 54, 5,
+          xml=np.frombuffer(xml.encode(), np.uint8))
 
 
 def photons():
@@ -251,6 +263,12 @@ def main():
         return photons_large()
     if "--textures" in sys.argv:
         return textures()
+    if "--lights" in sys.argv:
+        def image(name, scene, bundle, seed, mn, mx, delta, w, h, bounces, cwd=None, **extra):
+            img = run(scene, "render_whitted", seed, mn, mx, delta, w, h, bounces, cwd=cwd, harness=HARNESS_P12)
+            save(name, **bundle, **extra, params=np.array([seed, mn, mx, w, h, bounces], np.int64), delta=np.float32(delta), **img)
+        with tempfile.TemporaryDirectory() as tmp:
+            return lights(tmp, image)
     if "--whitted" in sys.argv:  # only the snapshot's fixtures
         return whitted()
     if "--photons" in sys.argv:

@@ -48,6 +48,13 @@ struct RayListIO {
     RT_DEV void put_shadow(uint32_t e, bool occluded) const { hit[e] = make_float4(occluded ? 1.0f : 0.0f, 0.0f, 0.0f, 0.0f); }
 };
 
+// The plain list through the four-wide walk, which the frames' extension and shadow rays take (WfIO, LaneIO): lets a
+// test send known rays through that walk and compare with the reference's answers (RT_QUERY_WIDE=1 makes
+// rt_trace_brief use it).  Same members as RayListIO, so the two are interchangeable as kernel arguments.
+struct RayListWideIO : RayListIO {
+    static constexpr bool kWide = true;
+};
+
 // The same list read and answered in the caller's own formats (six floats per ray, an optional t_max array,
 // rt_hit_brief records): nothing to convert on the host, so an entry point built on it needs no staging buffers.
 struct BriefIO {

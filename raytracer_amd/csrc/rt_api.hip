@@ -85,6 +85,7 @@ struct rt_ctx {
     uint32_t finish_below = 0; // RT_FINISH_BELOW: paths left in a round at which the wavefront pipeline hands over to k_wf_finish (default: 512 per CU; measured 8 k / 32 k / 128 k / 512 k: 101.3 / 99.8 / 98.3 / 99.2 ms per 1080p frame, 20.3 / 19.3 / 17.9 / 19.1 ms on an eighth of it)
     int pipeline = -1; // RT_PIPELINE: 0 = lock-step path kernel (k_paths), 1 = wavefront; -1: chosen per scene (wavefront when it has meshes)
     size_t ovf_threads = 0;
+    bool query_wide = false;  // RT_QUERY_WIDE=1: rt_trace_brief goes through the four-wide walk of the frames' rays (a test gate; the answers may differ from the reference's in the last bit of t)
     bool gpu_bvh = false;     // RT_GPU_BVH=1: build every mesh's BVH on the GPU even if the scene brings one
     double bvh_build_ms = 0;  // GPU time of the last upload's BVH builds
     int tlas_min_objects = 16; // RT_TLAS_MIN: object nodes from which a scene gets the hierarchy over their boxes (0 = never).  The reference's own scene (nine objects, five of them the walls of a box every ray is inside of) is slower through it: 38 -> 56 ms per frame
@@ -247,6 +248,14 @@ const void *rays_kernel(bool counting, int ray_levels)
     if (ray_levels <= 1) return counting ? (const void *)k_rays<true, 1, RayListIO> : (const void *)k_rays<false, 1, RayListIO>;
     if (ray_levels == 2) return counting ? (const void *)k_rays<true, 2, RayListIO> : (const void *)k_rays<false, 2, RayListIO>;
     return counting ? (const void *)k_rays<true, 5, RayListIO> : (const void *)k_rays<false, 5, RayListIO>;
+}
+
+// rt_trace_brief through the four-wide walk (RT_QUERY_WIDE=1; the counting variant always walks the binary tree)
+const void *rays_kernel_wide(int ray_levels)
+{
+    if (ray_levels <= 1) return (const void *)k_rays<false, 1, RayListWideIO>;
+    if (ray_levels == 2) return (const void *)k_rays<false, 2, RayListWideIO>;
+    return (const void *)k_rays<false, 5, RayListWideIO>;
 }
 
 const void *wf_trace_kernel(bool counting, int ray_levels)
@@ -455,7 +464,8 @@ int rt_init(int device, rt_ctx **out)
                           (const void *)k_order_keys<1>, (const void *)k_order_keys<2>, (const void *)k_order_keys<5>,
                           (const void *)k_trace, (const void *)k_trace_shadow, (const void *)k_trace_paths})
         (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    for (const void *k : {(const void *)k_rays<false, 1, BriefIO>, (const void *)k_rays<false, 2, BriefIO>, (const void *)k_rays<false, 5, BriefIO>})
+    for (const void *k : {(const void *)k_rays<false, 1, BriefIO>, (const void *)k_rays<false, 2, BriefIO>, (const void *)k_rays<false, 5, BriefIO>,
+                          (const void *)k_rays<false, 1, RayListWideIO>, (const void *)k_rays<false, 2, RayListWideIO>, (const void *)k_rays<false, 5, RayListWideIO>})
         (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     for (const void *k : {(const void *)k_photon_paths<false, 1>, (const void *)k_photon_paths<false, 2>, (const void *)k_photon_paths<false, 5>,
                           (const void *)k_photon_paths<true, 1>, (const void *)k_photon_paths<true, 2>, (const void *)k_photon_paths<true, 5>,
@@ -472,6 +482,7 @@ int rt_init(int device, rt_ctx **out)
     if (const char *e8 = getenv("RT_CHUNK_ITEMS")) ctx->chunk_items = std::max(0, atoi(e8)) / 64 * 64;
     if (const char *e7 = getenv("RT_ORDER")) ctx->order_pixels = atoi(e7) != 0 ? 1 : 0;
     if (const char *e11 = getenv("RT_GPU_BVH")) ctx->gpu_bvh = atoi(e11) != 0;
+    if (const char *e12 = getenv("RT_QUERY_WIDE")) ctx->query_wide = atoi(e12) != 0;
     if (const char *e10 = getenv("RT_TLAS_MIN")) ctx->tlas_min_objects = std::max(0, atoi(e10));
     if (const char *e2 = getenv("RT_LDS_LEVELS")) ctx->lds_levels_max = std::max(1, std::min(64, atoi(e2))); // tuning knob
     if ((e = ctx->d_queue.reserve(kQueueBytes)) != hipSuccess) return bail("hipMalloc", e);
@@ -1436,7 +1447,7 @@ int rt_trace_brief(rt_ctx *ctx, const float *rays6, const float *t_max, int n, r
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_q_in.p, od.data(), (size_t)n * 32, hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters.p, 0, sizeof(DCounters), s));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue.p, 0, kQueueBytes, s));
-    const void *fn = rays_kernel(ctx->counting, ctx->ray_levels);
+    const void *fn = ctx->query_wide && !ctx->counting ? rays_kernel_wide(ctx->ray_levels) : rays_kernel(ctx->counting, ctx->ray_levels);
     const size_t lds = stack_lds_bytes(ctx->scene);
     int per_cu = 1;
     HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kBlock, lds));
@@ -1445,6 +1456,7 @@ int rt_trace_brief(rt_ctx *ctx, const float *rays6, const float *t_max, int n, r
     const dim3 grid((unsigned)std::min<uint64_t>(want_blocks, (uint64_t)ctx->n_cu * per_cu));
     {
         DScene a_scene = ctx->scene;
+        static_assert(sizeof(RayListWideIO) == sizeof(RayListIO), "the two list policies are one kernel argument");
         RayListIO a_io{ctx->d_q_in.as<float4>(), ctx->d_q_in.as<float4>() + n, ctx->d_q_out.as<float4>(), ctx->d_q_aux.as<float>()};
         uint32_t a_n = (uint32_t)n;
         DCounters *a_ctr = ctx->d_counters.as<DCounters>();
@@ -1468,6 +1480,7 @@ int rt_trace_brief(rt_ctx *ctx, const float *rays6, const float *t_max, int n, r
     c = rt_counters{};
     c.closest_rays = dc.closest; c.shadow_rays = dc.shadow; c.box_tests = dc.box_tests; c.tri_tests = dc.tri_tests;
     c.kernel_ms = ms; c.trace_kernel_ms = ms; c.trace_launches = 1;
+    c.trace_pipeline = ctx->query_wide && !ctx->counting ? 2u : 0u;
     for (int i = 0; i < 16; ++i) c.phase_cycles[i] = dc.phase[i];
     for (int i = 0; i < n; ++i) {
         rt_hit_brief &o = out[i];

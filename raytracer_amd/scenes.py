@@ -225,6 +225,16 @@ def spheres_scene_xml(seed=1001, grid=8, width=1920, height=1080):
     return "\n".join(out)
 
 
+def lights_scene_xml(width=96, height=54, grid=3):
+    """The sphere grid lit by all three kinds of light the scene format has: the spherical light (first, as the
+    path integrator wants it), an ambient light and a directional one whose shadows fall across the floor."""
+    xml = spheres_scene_xml(seed=1001, grid=grid, width=width, height=height)
+    more = ('    <light type="ambient" name="ambientLight"><intensity r="0.12" g="0.15" b="0.2"/></light>\n'
+            '    <light type="direct" name="directLight"><intensity r="0.8" g="0.7" b="0.5"/>'
+            '<direction x="0.5" y="0.35" z="-1"/></light>\n')
+    return xml.replace("  </scene>", more + "  </scene>", 1)
+
+
 def nested_scene_xml(width=320, height=180):
     """Small closed room built from a two-level node hierarchy with rotations,
     non-uniform scales and a thin-lens camera; exercises every transform path."""

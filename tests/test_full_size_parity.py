@@ -230,6 +230,38 @@ def test_config_e_vs_reference(ctx):
     assert p >= PSNR_MIN, f"PSNR {p:.2f} dB vs the reference's band"
 
 
+def ulp_distance(a, b):
+    """Distance in representable floats between two arrays of positive finite floats (or equal bit patterns)."""
+    return np.abs(bits(a).astype(np.int64) - bits(b).astype(np.int64))
+
+
+@pytest.mark.gpu
+def test_wide_walk_against_the_references_rays():
+    """The four-wide BVH walk - what every extension and shadow ray of a mesh frame goes through, and what the
+    bit-exact tests above bypass (they use the binary walk, as the depth / id planes do) - on the reference's own
+    rays of the 1 M- and the 10 M-triangle scene and of the small mesh: the object hit must be the reference's for
+    every ray, every shadow answer too, and t may differ from the reference's by one ulp in at most two rays per set
+    (the wide walk takes children in distance order, so a box can be pruned against another "closest so far";
+    observed: one camera ray in twelve million)."""
+    mp = pytest.MonkeyPatch()
+    mp.setenv("RT_QUERY_WIDE", "1")
+    wide = lib.Context(0)
+    mp.undo()
+    try:
+        small = O.load_golden("kat_trace_mesh")
+        for hs_desc, g in ((scene_c()[0].desc, scene_c()[1]), (scene_e()[0].desc, scene_e()[1]), (O.scene_from_golden(small).desc, small)):
+            wide.upload(hs_desc)
+            got = wide.trace_brief(g["kat_rays"])
+            assert wide.counters().trace_pipeline == 2, "the query did not take the four-wide walk"
+            assert np.array_equal(got["node"], g["kat_id"]), "object hit"
+            d = ulp_distance(got["t"], g["kat_hit"][:, 0])
+            assert d.max() <= 1 and (d != 0).sum() <= 2, f"{(d != 0).sum()} rays differ in t, by up to {d.max()} ulp"
+            occ = wide.trace_brief(g["kat_rays"], g["kat_tmax"])
+            assert np.array_equal(occ["node"], g["kat_flags"][:, 2]), "shadow rays"
+    finally:
+        wide.close()
+
+
 @pytest.mark.gpu
 def test_small_mesh_goldens_with_this_context(ctx):
     """The 1024-triangle fixtures again (with three LDS levels their depth-10 BVH overflows too)."""
@@ -291,6 +323,74 @@ def test_photon_lookup_radii_vs_oracle(ctx, radius):
     assert np.array_equal(bits(e), bits(ref)), f"radius {radius}: {np.sum(np.any(bits(e) != bits(ref), axis=1))} of 600 estimates differ"
     if radius >= 3.0:
         assert (e.sum(axis=1) > 0).mean() > 0.5
+
+
+def check_kd_tree(tree):
+    """Heap-ordered kd-tree (entry i = node i + 1, children 2 i + 2 and 2 i + 3 in that numbering): every node lies
+    inside the slab each of its ancestors cuts off for it - left subtree at or below the ancestor's coordinate on its
+    plane, right subtree at or above (PhotonMap::BalanceSegment, src/photonmap.h:200-264).  Bounds are handed down
+    level by level."""
+    n = len(tree)
+    pos = tree["pos"]
+    plane = tree["plane"].astype(np.int64)
+    lo = np.full((n, 3), -np.inf, np.float32)
+    hi = np.full((n, 3), np.inf, np.float32)
+    first = 1
+    while first <= n:
+        ids = np.arange(first, min(2 * first, n + 1))  # heap numbers of this level
+        me = ids - 1
+        assert np.all(pos[me] >= lo[me]) and np.all(pos[me] <= hi[me]), f"a node of the level starting at {first} is on the wrong side of an ancestor's plane"
+        for side in (0, 1):
+            kid = 2 * ids + side
+            ok = kid <= n
+            k, par = kid[ok] - 1, me[ok]
+            assert np.all(plane[par] <= 2), "split axis out of range"
+            lo[k], hi[k] = lo[par], hi[par]
+            cut = pos[par, plane[par]]
+            (hi if side == 0 else lo)[k, plane[par]] = cut
+        first *= 2
+
+
+@pytest.mark.gpu
+def test_photon_maps_at_full_size():
+    """The photon-map configuration at its own size: 10 000 000 + 1 000 000 photons on the reference's scene (trees 24
+    and 20 levels tall), filled and balanced on the GPU.  Checked: both maps hold exactly the photons asked for; the
+    balanced arrays are kd-trees (check_kd_tree) whose photons are the emitted ones (same multiset of positions); two
+    fills give the same bits; 4096 irradiance estimates per map equal the oracle's lookups in the downloaded trees bit
+    for bit (the oracle's lookup is pinned by the reference's fixtures; its serial build of 10 M photons is not needed)."""
+    s = O.scene_from_golden(O.load_golden("scene_a"))
+    ctx = lib.Context(0)
+    try:
+        ctx.upload(s.desc)
+        pp = abi.PhotonParams(flags=abi.RT_PM_INDIRECT | abi.RT_PM_CAUSTICS, n_global=10_000_000, n_caustic=1_000_000, max_segments=64, seed=7)
+        ctx.photons_fill(pp)
+        rng = np.random.RandomState(5)
+        for which, want in ((abi.RT_MAP_GLOBAL, pp.n_global), (abi.RT_MAP_CAUSTICS, pp.n_caustic)):
+            tree = ctx.photons_download(which)
+            assert len(tree) == want
+            assert np.isfinite(tree["pos"]).all() and (tree["power"] > 0).all()
+            check_kd_tree(tree)
+            # lookups next to photons of every depth of the tree, normals against the photons' directions of travel
+            pick = rng.randint(0, len(tree), 4096)
+            pos = tree["pos"][pick] + rng.normal(0, 0.02, (4096, 3)).astype(np.float32)
+            nrm = -tree["dir"][pick]
+            got = ctx.photons_irradiance(which, pos, nrm, 3.0)
+            ref = O.photon_irradiance(tree, pos, nrm, 3.0)
+            assert np.array_equal(bits(got), bits(ref)), f"map {which}: {np.sum(np.any(bits(got) != bits(ref), axis=1))} of 4096 estimates differ"
+            assert (got.sum(axis=1) > 0).mean() > 0.9
+            if which == abi.RT_MAP_CAUSTICS:  # the emitted list again, unbalanced: the tree holds exactly these photons
+                raw, stored = ctx.photons_emit(pp, which, 0, 1 << 24, want)
+                if stored >= want:  # (the fill's rounds took at most this many paths)
+                    a = np.sort(np.ascontiguousarray(raw["pos"]).view([("x", "<f4"), ("y", "<f4"), ("z", "<f4")]).reshape(-1), order=["x", "y", "z"])
+                    b = np.sort(np.ascontiguousarray(tree["pos"]).view([("x", "<f4"), ("y", "<f4"), ("z", "<f4")]).reshape(-1), order=["x", "y", "z"])
+                    assert np.array_equal(a, b), "the balanced map does not hold the emitted photons"
+            if which == abi.RT_MAP_GLOBAL:  # fill both maps again: the same bits
+                first = photon_words(tree).copy()
+                del tree
+                ctx.photons_fill(pp)
+                assert np.array_equal(photon_words(ctx.photons_download(which)), first), "two fills differ"
+    finally:
+        ctx.close()
 
 
 @pytest.mark.gpu
@@ -375,6 +475,26 @@ def test_cancel_and_progress(scene):
         c.render(prm)  # the same frame, not cancelled, for the time it takes
         full = time.time() - full_t0
         assert dt < 0.6 * full + 0.05, f"cancelled call took {dt:.3f} s, the whole frame takes {full:.3f} s"
+    finally:
+        c.close()
+
+
+@pytest.mark.gpu
+def test_a_stale_cancel_does_not_shorten_the_next_emission():
+    """rt_cancel while nothing runs (a viewer's Stop racing with the end of a frame) must not leak into the next call:
+    rt_photons_emit called directly starts with a clear flag and stores what it stores without the request."""
+    c = lib.Context(0)
+    try:
+        c.upload(O.scene_from_golden(O.load_golden("scene_a")).desc)
+        pp = abi.PhotonParams(flags=abi.RT_PM_INDIRECT | abi.RT_PM_CAUSTICS, n_global=20000, n_caustic=2000, max_segments=64, seed=3)
+        want, n_want = c.photons_emit(pp, abi.RT_MAP_GLOBAL, 0, 30000, 20000)
+        assert n_want > 10000
+        assert c.cancel() == 0
+        got, n_got = c.photons_emit(pp, abi.RT_MAP_GLOBAL, 0, 30000, 20000)
+        assert n_got == n_want and np.array_equal(photon_words(got), photon_words(want))
+        assert c.cancel() == 0
+        c.photons_fill(pp)  # and a fill after a stale request runs to its end
+        assert len(c.photons_download(abi.RT_MAP_GLOBAL)) == 20000
     finally:
         c.close()
 

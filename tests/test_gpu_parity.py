@@ -179,7 +179,7 @@ def test_mesh_scene_vs_oracle_with_counters(ctx):
 
 
 WHITTED = ["whitted_a_96x54_b0", "whitted_a_96x54_b5", "whitted_a_64x36_adaptive", "whitted_spheres_96x54_b0",
-           "whitted_mesh_96x54_b5"]
+           "whitted_mesh_96x54_b5", "whitted_lights_96x54_b5"]  # the last: ambient + directional + spherical light
 
 
 @pytest.mark.parametrize("name", WHITTED)

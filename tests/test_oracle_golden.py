@@ -149,7 +149,7 @@ def test_seeded_images(name):
 
 
 WHITTED = ["whitted_a_96x54_b0", "whitted_a_96x54_b5", "whitted_a_64x36_adaptive", "whitted_spheres_96x54_b0",
-           "whitted_mesh_96x54_b5"]
+           "whitted_mesh_96x54_b5", "whitted_lights_96x54_b5"]  # the last: ambient + directional + spherical light
 
 
 @pytest.mark.parametrize("name", WHITTED)
@@ -175,6 +175,24 @@ def test_whitted_images(name):
         b0 = abi.default_params(seed=seed, min_spp=mn, max_spp=mx, delta_max=float(g["delta"]), max_bounces=0,
                                 mode=abi.RT_MODE_WHITTED)
         assert np.abs(O.render(s, b0, w, h).linear - fr.linear).max() > 0.05
+
+
+def test_every_kind_of_light_shows_in_the_lights_golden():
+    """The golden with three lights would pin nothing if two of them added nothing: without the ambient light, and
+    without the directional one, the oracle's image of the same scene differs from the reference's clearly (the
+    light loop of the snapshot's shader, project12.zip src/materials.cpp:24-47, src/lights.h:28-56)."""
+    g = O.load_golden("whitted_lights_96x54_b5")
+    seed, mn, mx, w, h, bounces = [int(x) for x in g["params"]]
+    prm = abi.default_params(seed=seed, min_spp=mn, max_spp=mx, delta_max=float(g["delta"]), max_bounces=bounces, mode=abi.RT_MODE_WHITTED)
+    kinds = g["scene_lights"][:, 0].astype(int).tolist()
+    assert kinds == [abi.RT_LIGHT_POINT, abi.RT_LIGHT_AMBIENT, abi.RT_LIGHT_DIRECT]
+    for drop in (1, 2):
+        dark = dict(g)
+        dark["scene_lights"] = g["scene_lights"].copy()
+        dark["scene_lights"][drop, 1:4] = 0.0  # the light's intensity
+        s = O.scene_from_golden(dark)
+        diff = np.abs(O.render(s, prm, w, h).linear - g["linear"])
+        assert (diff.max(axis=-1) > 0.02).mean() > 0.25, f"light {drop} changes too little of the image"
 
 
 def photon_words(a):
