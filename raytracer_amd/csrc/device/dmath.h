@@ -10,6 +10,7 @@
 #include <stdint.h>
 
 #define RT_DEV __device__ __forceinline__
+#define RT_HD __host__ __device__ inline
 
 namespace rtd {
 

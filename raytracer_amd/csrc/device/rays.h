@@ -16,6 +16,13 @@
 //   kDeferShadow, Pending, begin_put_shadow(tag, pending), end_put_shadow(tag, pending): an IO that has to read
 //   something before it can take the answer "not occluded" splits the hand-over into its loads and its stores; the
 //   kernel issues the loads, then the loads of the lane's next ray, and only then asks for the stores
+//   uint32_t setup(n)                          called once per thread before anything else: the length of the list (an IO
+//                                              whose lists have their lengths in device memory reads them here)
+//   kCarry, carried(tag), give_up(tag)         an IO that can take "not now" for an answer: near the end of a launch, when
+//                                              the list is empty and a wave is down to a few lanes, a closest-hit ray that
+//                                              is still walking is handed back unanswered, to be traced again in the next
+//                                              launch - a launch otherwise ends when its longest ray does, with the chip idle
+//                                              (carried(tag): this ray has been handed back once already, answer it)
 #pragma once
 #include "kernels.h"
 
@@ -27,7 +34,11 @@ struct NoPending {};
 struct RayListIO {
     static constexpr bool kWide = false; // the reference's binary walk
     static constexpr bool kDeferShadow = false;
+    static constexpr bool kCarry = false;
     typedef NoPending Pending;
+    RT_DEV uint32_t setup(uint32_t n) { return n; }
+    RT_DEV bool carried(uint32_t) const { return true; }
+    RT_DEV void give_up(uint32_t) const {}
     RT_DEV void begin_put_shadow(uint32_t, Pending &) const {}
     RT_DEV void end_put_shadow(uint32_t, const Pending &) const {}
     const float4 *ray_o, *ray_d;
@@ -60,7 +71,11 @@ struct RayListWideIO : RayListIO {
 struct BriefIO {
     static constexpr bool kWide = false;
     static constexpr bool kDeferShadow = false;
+    static constexpr bool kCarry = false;
     typedef NoPending Pending;
+    RT_DEV uint32_t setup(uint32_t n) { return n; }
+    RT_DEV bool carried(uint32_t) const { return true; }
+    RT_DEV void give_up(uint32_t) const {}
     RT_DEV void begin_put_shadow(uint32_t, Pending &) const {}
     RT_DEV void end_put_shadow(uint32_t, const Pending &) const {}
     const float *rays6, *t_max; // t_max null: closest hits
@@ -100,6 +115,14 @@ struct BriefIO {
 #endif
 #ifndef RT_RAYS_REFILL_MIN_LANES
 #define RT_RAYS_REFILL_MIN_LANES 24 // fetch new rays once this many lanes are idle
+#endif
+// Handing rays back at the end of a launch (IO::kCarry): once the list is empty, a wave that has gone this many trips
+// further and is down to this many lanes hands its closest-hit rays back (0 lanes: never)
+#ifndef RT_CARRY_AFTER_TRIPS
+#define RT_CARRY_AFTER_TRIPS 32
+#endif
+#ifndef RT_CARRY_MAX_LANES
+#define RT_CARRY_MAX_LANES 8
 #endif
 
 // Records of the four-wide BVH kept in LDS by the ray-list kernel: the top levels of the scene's largest mesh, which
@@ -397,10 +420,37 @@ template <bool COUNT, int LEVELS, class IO> struct RayWalker {
 // The list is handed out in chunks of ray_chunk entries, one atomic per chunk and wave.  (Cutting the list into
 // eight parts with a queue word each, so that each XCD's L2 sees the rays of one eighth of the image, was measured:
 // 88.6 against 89.0 ms of ray launches per 1080p frame, not worth the index arithmetic in the refill step.)
+#ifndef RT_PORTION_DIV
+#define RT_PORTION_DIV 8
+#endif
+#ifndef RT_PORTION_MAX
+#define RT_PORTION_MAX 1024
+#endif
+// rays a wave reserves per queue atomic: few atomics on the queue word in large launches, enough portions for every
+// wave (and an even end) in small ones - about an eighth of a wave's share of the list
+RT_HD uint32_t ray_portion(uint64_t n_rays, unsigned grid_blocks)
+{
+    const uint64_t per_wave = n_rays / ((uint64_t)grid_blocks * (kBlock / 64)) / RT_PORTION_DIV;
+    return per_wave >= RT_PORTION_MAX ? (uint32_t)RT_PORTION_MAX : per_wave >= 4096 ? 4096u : per_wave >= 2048 ? 2048u : per_wave >= 1024 ? 1024u : per_wave >= 512 ? 512u : per_wave >= 256 ? 256u : per_wave >= 128 ? 128u : 64u;
+}
+
+// ray_chunk 0: sized here from the length of the list (ray_portion)
 template <bool COUNT, int LEVELS, class IO>
-__global__ __launch_bounds__(kBlock, RT_RAYS_MIN_WAVES) void k_rays(DScene S, IO io, uint32_t n_rays, DCounters *ctr,
+__global__ __launch_bounds__(kBlock, RT_RAYS_MIN_WAVES) void k_rays(DScene S, IO io_arg, uint32_t n_rays_arg, DCounters *ctr,
                                                                   unsigned long long *queue, uint32_t ray_chunk)
 {
+    IO io = io_arg;
+    const uint32_t n_rays = io.setup(n_rays_arg);
+    if (ray_chunk == 0) ray_chunk = ray_portion(n_rays, gridDim.x);
+    constexpr bool kCarry = IO::kCarry && !COUNT && RT_CARRY_MAX_LANES > 0; // (a ray traced twice would count its box and triangle tests twice)
+    uint32_t late_trips = 0;
+#ifdef RT_PROFILE_TAIL
+    // diagnostic build: when do the waves of one launch (the one launched with n_rays_arg == RT_PROFILE_TAIL) start,
+    // run out of list, and end?  phase[0] earliest start, [1] latest end, [2] sum of starts, [3] sum of the moments the
+    // list was found empty, [4] sum of ends, [5] waves, [6] latest "list empty", [7] earliest "list empty" (100 MHz clock)
+    const unsigned long long tail_t0 = wall_clock64();
+    unsigned long long tail_tx = 0;
+#endif
     extern __shared__ uint32_t lds[];
     const LaneStack st = lane_stack(lds, S);
     const uint32_t lane = threadIdx.x & 63u;
@@ -415,8 +465,16 @@ __global__ __launch_bounds__(kBlock, RT_RAYS_MIN_WAVES) void k_rays(DScene S, IO
         __syncthreads();
     }
 
-    // wave-uniform window of the ray list
-    uint32_t chunk_next = 0, chunk_end = 0;
+    // The list is handed out in portions of ray_chunk entries, one global atomic per portion; a portion belongs to the
+    // WORKGROUP, whose waves draw their rays from it as their lanes fall idle (one LDS atomic per refill).  A portion
+    // is a few neighbouring pixels' rays, and cost is a matter of place (rays along a mesh's rim take fifteen times
+    // the average): with a portion per wave, the wave that drew a bad one late in the launch kept the chip waiting for
+    // up to four rays per lane, one after the other; shared, it is one ray per lane, and the waves still work on
+    // neighbouring rays.  s_win = end << 32 | next: entries [next, end) of the list are the workgroup's to take.
+    __shared__ unsigned long long s_win;
+    __shared__ uint32_t s_lock, s_done; // one wave at a time fetches the next portion; the list has run out
+    if (threadIdx.x == 0) { s_win = 0; s_lock = 0; s_done = 0; }
+    __syncthreads();
     bool exhausted = false;
 
     // A lane is idle, stepping through the scene nodes, walking a BVH, or parked at a leaf.  The wave
@@ -429,19 +487,62 @@ __global__ __launch_bounds__(kBlock, RT_RAYS_MIN_WAVES) void k_rays(DScene S, IO
         const uint64_t idle = __ballot(!w.active);
         pt.tock(12);
         if (idle != 0 && !exhausted && ((uint32_t)__popcll(idle) >= (uint32_t)RT_RAYS_REFILL_MIN_LANES || !__any(w.in_bvh))) {
-            if (chunk_next >= chunk_end) {
-                unsigned long long b = 0;
-                // (rt_cancel is not looked at here: a ray launch lasts milliseconds and the host checks between launches;
-                // reading the flag, which lives in host memory, at every draw cost the 1080p frame 13 ms)
-                if (lane == 0) b = atomicAdd(queue, (unsigned long long)ray_chunk);
-                b = __shfl(b, 0, 64);
-                chunk_next = b < n_rays ? (uint32_t)b : n_rays;
-                chunk_end = b + ray_chunk < n_rays ? (uint32_t)(b + ray_chunk) : n_rays;
-                if (chunk_next >= chunk_end) exhausted = true;
-            }
-            const uint32_t avail = chunk_end - chunk_next;
             const uint32_t want = (uint32_t)__popcll(idle);
-            const uint32_t take = avail < want ? avail : want;
+            uint32_t first = 0, take = 0;
+            {
+                unsigned long long old = 0;
+                if (lane == 0) old = atomicAdd(&s_win, (unsigned long long)want);
+                old = __shfl(old, 0, 64);
+                const uint32_t nx = (uint32_t)old, en = (uint32_t)(old >> 32);
+                if (nx < en) { first = nx; take = en - nx < want ? en - nx : want; }
+                else {
+                    // the portion is used up: one wave fetches the next (the others come back at their next trip)
+                    uint32_t got_lock = 0;
+                    if (lane == 0) got_lock = (__hip_atomic_load(&s_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u && atomicCAS(&s_lock, 0u, 1u) == 0u) ? 1u : 0u;
+                    got_lock = __shfl(got_lock, 0, 64);
+                    if (got_lock) {
+                        // (rt_cancel is not looked at here: a ray launch lasts milliseconds and the host checks between launches;
+                        // reading the flag, which lives in host memory, at every draw cost the 1080p frame 13 ms)
+                        unsigned long long b = 0;
+                        if (lane == 0) {
+                            // another wave may have fetched a portion between this wave's look at the window and its taking the lock
+                            const unsigned long long now = __hip_atomic_load(&s_win, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if ((uint32_t)now >= (uint32_t)(now >> 32)) {
+                                b = atomicAdd(queue, (unsigned long long)ray_chunk);
+                                if (b < n_rays) {
+                                    const uint32_t e = b + ray_chunk < n_rays ? (uint32_t)(b + ray_chunk) : n_rays;
+                                    // this wave's own share comes off the new portion before the others see it
+                                    const uint32_t mine = e - (uint32_t)b < want ? e - (uint32_t)b : want;
+                                    atomicExch(&s_win, ((unsigned long long)e << 32) | ((uint32_t)b + mine));
+                                    b = ((unsigned long long)mine << 32) | (uint32_t)b;
+                                } else {
+                                    __hip_atomic_store(&s_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    b = 0;
+                                }
+                            }
+                            __hip_atomic_store(&s_lock, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                        b = __shfl(b, 0, 64);
+                        first = (uint32_t)b; take = (uint32_t)(b >> 32);
+                    }
+                    if (take == 0) {
+                        uint32_t done = 0;
+                        if (lane == 0) done = __hip_atomic_load(&s_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (__shfl(done, 0, 64)) {
+                            // the list has run out - unless a last portion came in just before: look once more
+                            unsigned long long now = 0;
+                            if (lane == 0) now = __hip_atomic_load(&s_win, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            now = __shfl(now, 0, 64);
+                            if ((uint32_t)now >= (uint32_t)(now >> 32)) {
+                                exhausted = true;
+#ifdef RT_PROFILE_TAIL
+                                if (tail_tx == 0) tail_tx = wall_clock64();
+#endif
+                            }
+                        }
+                    }
+                }
+            }
             const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
             const bool taking = !w.active && rank < take;
             typename IO::Pending pend; // what the lane's finished shadow ray still has to hand over: its loads go out first
@@ -449,24 +550,44 @@ __global__ __launch_bounds__(kBlock, RT_RAYS_MIN_WAVES) void k_rays(DScene S, IO
             if (owes) io.begin_put_shadow(w.tag, pend);
             if (!w.active && w.finished) w.finish_closest(S, io);
             if (taking) {
-                const uint32_t e = chunk_next + rank;
+                const uint32_t e = first + rank;
                 float4 o, d; bool shadow; float tmax; uint32_t tg;
                 const uint32_t old = w.tag;
                 const bool got = io.fetch(e, o, d, shadow, tmax, tg); // a list may have holes
                 if (owes) { io.end_put_shadow(old, pend); w.unoccluded = false; }
                 if (got) w.start(tg, o, d, shadow, tmax, pt);
             } else if (owes) { io.end_put_shadow(w.tag, pend); w.unoccluded = false; }
-            chunk_next += take;
             pt.ran(0, idle);
         }
         if (!__any(w.active)) {
             if (exhausted) break; // every wave gets here: the queue word only grows
             continue;
         }
+        if (kCarry && exhausted && ++late_trips > (uint32_t)RT_CARRY_AFTER_TRIPS &&
+            (uint32_t)__popcll(__ballot(w.active)) <= (uint32_t)RT_CARRY_MAX_LANES) {
+            // the list is empty, the wave nearly so, and these rays have had their time: hand the closest-hit rays back
+            // unanswered (shadow rays are short and their answers are due in this launch: they stay)
+            if (w.active && !w.any_hit && !io.carried(w.tag)) {
+                io.give_up(w.tag);
+                --pt.closest; // counted when it is traced again
+                w.active = false; w.in_bvh = false; w.at_leaf = false; w.finished = false; w.cur = kNoNode; w.sp = 0;
+            }
+            if (!__any(w.active)) break;
+        }
         w.phases(S, io, st, top4, pt, tl);
     }
     if (IO::kDeferShadow && w.unoccluded) { typename IO::Pending pend; io.begin_put_shadow(w.tag, pend); io.end_put_shadow(w.tag, pend); }
     if (w.finished) w.finish_closest(S, io);
+#ifdef RT_PROFILE_TAIL
+    if (lane == 0 && n_rays_arg == (uint32_t)(RT_PROFILE_TAIL)) {
+        const unsigned long long t1 = wall_clock64();
+        if (tail_tx == 0) tail_tx = t1;
+        atomicMin(&ctr->phase[0], tail_t0); atomicMax(&ctr->phase[1], t1);
+        atomicAdd(&ctr->phase[2], tail_t0); atomicAdd(&ctr->phase[3], tail_tx); atomicAdd(&ctr->phase[4], t1);
+        atomicAdd(&ctr->phase[5], 1ull);
+        atomicMax(&ctr->phase[6], tail_tx); atomicMin(&ctr->phase[7], tail_tx);
+    }
+#endif
     flush_counters<COUNT>(ctr, pt, tl, 0);
 }
 

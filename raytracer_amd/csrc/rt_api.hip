@@ -25,6 +25,8 @@ using namespace rtd;
 namespace {
 
 thread_local std::string g_init_error;
+// dynamic LDS a kernel may ask for: the CU's 160 KiB less what kernels declare statically (work-queue windows, list staging)
+constexpr int kMaxDynamicLds = 160 * 1024 - 1024;
 
 struct DeviceBuf {
     void *p = nullptr;
@@ -79,7 +81,7 @@ struct rt_ctx {
     int order_pixels = -1;    // RT_ORDER: 1 = always deal a frame's pixels expensive-first, 0 = never (tile order), default: for tile shards only
     DeviceBuf d_stack_ovf;
     // wavefront pipeline (device/wavefront.h): per-slot path state, the bounce lists, list counts, event pairs around the ray launches
-    DeviceBuf d_wf_state, d_wf_queue[2], d_wf_sh_queue, d_wf_counts;
+    DeviceBuf d_wf_state, d_wf_queue[2], d_wf_carry[2], d_wf_sh_queue, d_wf_counts;
     static constexpr int kMaxRayLaunches = 96;
     hipEvent_t ray_ev[2 * kMaxRayLaunches] = {};
     uint32_t finish_below = 0; // RT_FINISH_BELOW: paths left in a round at which the wavefront pipeline hands over to k_wf_finish (default: 512 per CU; measured 8 k / 32 k / 128 k / 512 k: 101.3 / 99.8 / 98.3 / 99.2 ms per 1080p frame, 20.3 / 19.3 / 17.9 / 19.1 ms on an eighth of it)
@@ -102,7 +104,7 @@ struct rt_ctx {
     rt_photon *pmap(int which) const { return (rt_photon *)((char *)d_pmap[which].p + sizeof(rt_photon)); }
     int pmap_flags = -1; // RT_PM_* bits the maps were filled with, -1 = not known (built from caller's photons)
     std::vector<int32_t> active_host;
-    int active_key[5] = {-1, -1, -1, -1, -1};
+    int active_key[6] = {-1, -1, -1, -1, -1, -1};
     rt_counters counters{};
 
     // rt_cancel / rt_progress: the only state another thread may touch while a call runs on this context
@@ -265,14 +267,6 @@ const void *wf_trace_kernel(bool counting, int ray_levels)
     return counting ? (const void *)k_rays<true, 5, WfIO> : (const void *)k_rays<false, 5, WfIO>;
 }
 
-// rays a wave of the ray-list kernel reserves per queue atomic: few atomics on the queue word in large launches, enough
-// portions for every wave (and an even end) in small ones - about an eighth of a wave's share of the list
-uint32_t ray_portion(uint64_t n_rays, unsigned grid_blocks)
-{
-    const uint64_t per_wave = n_rays / ((uint64_t)grid_blocks * (kBlock / 64)) / 8;
-    return per_wave >= 1024 ? 1024u : per_wave >= 512 ? 512u : per_wave >= 256 ? 256u : per_wave >= 128 ? 128u : 64u;
-}
-
 size_t stack_lds_bytes(const DScene &S) { return (size_t)S.lds_levels * kBlock * 8; }
 // kernels that look photons up keep the arrays of found photons of kGatherSlots lanes per wave behind the stacks
 size_t gather_lds_bytes(const DScene &S) { return stack_lds_bytes(S) + kHeapLdsBytes; }
@@ -280,10 +274,12 @@ size_t gather_lds_bytes(const DScene &S) { return stack_lds_bytes(S) + kHeapLdsB
 } // namespace
 
 // One sampling round of `items` camera paths through the wavefront pipeline (device/wavefront.h): camera rays, then per
-// bounce one ray launch (extension rays of the live paths + shadow rays of the previous bounce) and one shading launch,
-// until no path and no shadow ray is left.  The host reads the two list counts after every shading launch.
+// bounce one ray launch (extension rays handed back by the previous launch, extension rays of the live paths, shadow
+// rays of the previous bounce) and one shading launch, until no path and no shadow ray is left.  The lists' lengths stay
+// in device memory, one WfCounts per bounce, where the kernels read them; the host reads them too, after every shading
+// launch, to size the next launches and to see when to hand over to k_wf_finish.
 static int render_wavefront(rt_ctx *ctx, const DFrame &F, const int32_t *act, uint64_t items64, int k0, int nk,
-                            const FramePlanes &planes, size_t lds, double *ray_ms, uint32_t *ray_launches)
+                            const FramePlanes &planes, size_t lds, double *ray_ms, uint32_t *ray_launches, uint64_t *carried)
 {
     hipStream_t s = ctx->stream;
     const uint32_t items = (uint32_t)items64;
@@ -293,8 +289,13 @@ static int render_wavefront(rt_ctx *ctx, const DFrame &F, const int32_t *act, ui
     for (int i = 0; i < 9; ++i) { offs[i] = total; total += ((size_t)items * sizes[i] + 255) / 256 * 256; }
     HIP_TRY(ctx, ctx->d_wf_state.reserve(total));
     for (auto &q : ctx->d_wf_queue) HIP_TRY(ctx, q.reserve((size_t)items * 4));
+    for (auto &q : ctx->d_wf_carry) HIP_TRY(ctx, q.reserve((size_t)items * 4));
     HIP_TRY(ctx, ctx->d_wf_sh_queue.reserve((size_t)items * 4));
-    HIP_TRY(ctx, ctx->d_wf_counts.reserve(256));
+    // a path falls behind its bounce number by one launch each time its ray is handed back, at most once per bounce
+    const int n_entries = 2 * F.max_bounces + 8;
+    HIP_TRY(ctx, ctx->d_wf_counts.reserve((size_t)n_entries * sizeof(WfCounts)));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_wf_counts.p, 0, (size_t)n_entries * sizeof(WfCounts), s));
+    WfCounts *const cnt = ctx->d_wf_counts.as<WfCounts>();
     char *base = ctx->d_wf_state.as<char>();
     WfState P;
     P.ray_o = (float4 *)(base + offs[0]); P.ray_d = (float4 *)(base + offs[1]); P.thr = (float4 *)(base + offs[2]);
@@ -315,7 +316,7 @@ static int render_wavefront(rt_ctx *ctx, const DFrame &F, const int32_t *act, ui
         HIP_TRY(ctx, hipLaunchKernel(fp, grid, dim3(kBlock), pargs, lds, s));
     }
     const dim3 wide((unsigned)std::min<uint64_t>(((uint64_t)items + kBlock - 1) / kBlock, (uint64_t)ctx->n_cu * 32));
-    hipLaunchKernelGGL(k_wf_generate, wide, dim3(kBlock), 0, s, F, ctx->d_halton.as<float>(), act, items, k0, nk, P);
+    hipLaunchKernelGGL(k_wf_generate, wide, dim3(kBlock), 0, s, F, ctx->d_halton.as<float>(), act, items, k0, nk, P, cnt);
     HIP_TRY(ctx, hipGetLastError());
 
     const void *fn = wf_trace_kernel(ctx->counting, ctx->ray_levels);
@@ -326,61 +327,69 @@ static int render_wavefront(rt_ctx *ctx, const DFrame &F, const int32_t *act, ui
     DScene a_scene = ctx->scene;
     DCounters *a_ctr = ctx->d_counters.as<DCounters>();
     unsigned long long *a_queue = ctx->d_queue.as<unsigned long long>();
-    uint32_t *counts = ctx->d_wf_counts.as<uint32_t>();
+    uint32_t *const sh_queue = ctx->d_wf_sh_queue.as<uint32_t>();
+    int launch = 0;
+    // one ray launch over the lists of bounce b (n_rays: what the host knows of their total length, for the grid)
+    const auto launch_rays = [&](int b, const uint32_t *queue_in, uint64_t n_rays, bool shadows_only) -> int {
+        const dim3 grid((unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_rays + kBlock - 1) / kBlock, (uint64_t)ctx->n_cu * per_cu)));
+        WfIO a_io{P, queue_in, ctx->d_wf_carry[b & 1].as<uint32_t>(), sh_queue, cnt + b, shadows_only ? 1u : 0u, 0u, 0u};
+        uint32_t a_n = (uint32_t)b, a_chunk = 0; // the kernel takes the list's length from cnt[b] and sizes the portions itself (the bounce number only serves diagnostic builds)
+        void *targs[] = {&a_scene, &a_io, &a_n, &a_ctr, &a_queue, &a_chunk};
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue.p, 0, kQueueBytes, s));
+        const bool timed = launch < rt_ctx::kMaxRayLaunches;
+        if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ray_ev[2 * launch], s));
+        HIP_TRY(ctx, hipLaunchKernel(fn, grid, dim3(kBlock), targs, lds_rays, s));
+        if (timed) { HIP_TRY(ctx, hipEventRecord(ctx->ray_ev[2 * launch + 1], s)); ++launch; }
+        return RT_OK;
+    };
 
-    uint32_t n_ext = items, n_sh = 0, held_ext = 0;
+    WfCounts h{items, 0u, 0u, 0u}; // the host's copy of cnt[b]
     bool finishing = false;
-    int cur = 0, launch = 0;
+    int cur = 0;
     const uint32_t *queue_in = nullptr; // the camera rays: slot e
-    for (int bounce = 0; n_ext + n_sh > 0 || finishing; ++bounce) {
-        if (n_ext + n_sh > 0) { // extension rays of this bounce, shadow rays of the previous one
-            const uint64_t n_rays = (uint64_t)n_ext + n_sh;
-            const dim3 grid((unsigned)std::min<uint64_t>((n_rays + kBlock - 1) / kBlock, (uint64_t)ctx->n_cu * per_cu));
-            WfIO a_io{P, queue_in, ctx->d_wf_sh_queue.as<uint32_t>(), n_ext};
-            uint32_t a_n = (uint32_t)n_rays;
-            // rays a wave reserves at a time: few atomics on the queue word in the large launches, enough chunks for every wave in the small ones
-            uint32_t a_chunk = ray_portion(n_rays, grid.x);
-            void *targs[] = {&a_scene, &a_io, &a_n, &a_ctr, &a_queue, &a_chunk};
-            HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue.p, 0, kQueueBytes, s));
-            const bool timed = launch < rt_ctx::kMaxRayLaunches;
-            if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ray_ev[2 * launch], s));
-            HIP_TRY(ctx, hipLaunchKernel(fn, grid, dim3(kBlock), targs, lds_rays, s));
-            if (timed) { HIP_TRY(ctx, hipEventRecord(ctx->ray_ev[2 * launch + 1], s)); ++launch; }
-        }
-        if (finishing) n_ext = held_ext;
-        if (n_ext == 0) break; // those were the last shadow rays
-        if (finishing) { // the shadow rays of the last shaded bounce are in; the remaining paths run to their ends in one launch
+    for (int b = 0;; ++b) {
+        const uint64_t n_live = (uint64_t)h.n_ext + h.n_carry;
+        if (finishing) { // the shadow rays of the last shaded bounce, then the remaining paths to their ends in one launch
+            if (h.n_shadow > 0) if (int rc = launch_rays(b, queue_in, h.n_shadow, true)) return rc;
             const void *ff = ctx->counting ? (ctx->ray_levels <= 1 ? (const void *)k_wf_finish<true, 1> : ctx->ray_levels == 2 ? (const void *)k_wf_finish<true, 2> : (const void *)k_wf_finish<true, 5>)
                                            : (ctx->ray_levels <= 1 ? (const void *)k_wf_finish<false, 1> : ctx->ray_levels == 2 ? (const void *)k_wf_finish<false, 2> : (const void *)k_wf_finish<false, 5>);
             // a pair of lanes per path
-            const dim3 grid((unsigned)std::min<uint64_t>(((uint64_t)n_ext * 2 + kBlock - 1) / kBlock, ctx->ovf_threads / kBlock));
+            const dim3 grid((unsigned)std::min<uint64_t>((n_live * 2 + kBlock - 1) / kBlock, ctx->ovf_threads / kBlock));
             DFrame f_frame = F;
             int f_k0 = k0, f_nk = nk;
-            uint32_t f_n = n_ext;
+            const uint32_t *f_carry = ctx->d_wf_carry[b & 1].as<uint32_t>();
+            const WfCounts *f_cnt = cnt + b;
             HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue.p, 0, kQueueBytes, s));
-            void *fargs[] = {&a_scene, &f_frame, &f_k0, &f_nk, &P, &queue_in, &f_n, &a_ctr, &a_queue};
+            void *fargs[] = {&a_scene, &f_frame, &f_k0, &f_nk, &P, &queue_in, &f_carry, &f_cnt, &a_ctr, &a_queue};
             HIP_TRY(ctx, hipLaunchKernel(ff, grid, dim3(kBlock), fargs, lds, s));
             ctx->prog_round_done.store(items);
             break;
         }
-        HIP_TRY(ctx, hipMemsetAsync(counts, 0, 8, s));
+        if (n_live + h.n_shadow == 0) break;
+        if (int rc = launch_rays(b, queue_in, n_live + h.n_shadow, false)) return rc;
+        if (n_live == 0) break; // those were the last shadow rays
         {
-            const dim3 grid((unsigned)std::min<uint64_t>(((uint64_t)n_ext + kShadeChunk - 1) / kShadeChunk, (uint64_t)ctx->n_cu * 16));
-            uint32_t *queue_out = ctx->d_wf_queue[cur].as<uint32_t>(), *sh_out = ctx->d_wf_sh_queue.as<uint32_t>();
-            if (bounce == 0) hipLaunchKernelGGL(k_wf_shade<true>, grid, dim3(kBlock), 0, s, a_scene, F, act, k0, nk, P, queue_in, n_ext, queue_out, sh_out, counts, planes);
-            else hipLaunchKernelGGL(k_wf_shade<false>, grid, dim3(kBlock), 0, s, a_scene, F, act, k0, nk, P, queue_in, n_ext, queue_out, sh_out, counts, planes);
+            const dim3 grid((unsigned)std::min<uint64_t>((n_live + kShadeChunk - 1) / kShadeChunk, (uint64_t)ctx->n_cu * 16));
+            uint32_t *queue_out = ctx->d_wf_queue[cur].as<uint32_t>();
+            const uint32_t *carry_in = ctx->d_wf_carry[b & 1].as<uint32_t>();
+            uint32_t *carry_out = ctx->d_wf_carry[(b + 1) & 1].as<uint32_t>();
+            if (b == 0) hipLaunchKernelGGL(k_wf_shade<true>, grid, dim3(kBlock), 0, s, a_scene, F, act, k0, nk, P, queue_in, carry_in, cnt + b, queue_out, sh_queue, carry_out, cnt + b + 1, planes);
+            else hipLaunchKernelGGL(k_wf_shade<false>, grid, dim3(kBlock), 0, s, a_scene, F, act, k0, nk, P, queue_in, carry_in, cnt + b, queue_out, sh_queue, carry_out, cnt + b + 1, planes);
             HIP_TRY(ctx, hipGetLastError());
             queue_in = queue_out;
             cur ^= 1;
         }
-        // the two list lengths, into pinned memory (a pageable destination goes through a staging copy)
+        // the next bounce's list lengths, into pinned memory (a pageable destination goes through a staging copy)
         volatile uint32_t *got = (volatile uint32_t *)&ctx->host_words[2];
-        HIP_TRY(ctx, hipMemcpyAsync((void *)got, counts, 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipMemcpyAsync((void *)got, cnt + b + 1, sizeof(WfCounts), hipMemcpyDeviceToHost, s));
         HIP_TRY(ctx, hipStreamSynchronize(s));
-        n_ext = got[0]; n_sh = got[1];
-        ctx->prog_round_done.store(items - n_ext); // paths that have ended
-        // few paths left: their shadow rays next (a ray launch without extension rays), then k_wf_finish
-        if (n_ext > 0 && n_ext <= ctx->finish_below && bounce + 1 < F.max_bounces) { finishing = true; held_ext = n_ext; n_ext = 0; }
+        h = WfCounts{got[0], got[1], got[2], 0u};
+        *carried += h.n_carry;
+        const uint64_t left = (uint64_t)h.n_ext + h.n_carry;
+        ctx->prog_round_done.store(items - std::min<uint64_t>(items, left)); // paths that have ended
+        // few paths left: their shadow rays next (a ray launch without extension rays), then k_wf_finish; the same when
+        // the array of list lengths is about to run out (paths handed back over and over: the finisher takes them all)
+        if (left > 0 && (left <= ctx->finish_below || b + 3 >= n_entries)) finishing = true;
         if (cancelled(ctx)) break; // the round's kernels hand out no more rays; rt_render reports the cancellation
     }
     HIP_TRY(ctx, hipStreamSynchronize(s));
@@ -463,14 +472,15 @@ int rt_init(int device, rt_ctx **out)
                           (const void *)k_wf_finish<true, 1>, (const void *)k_wf_finish<true, 2>, (const void *)k_wf_finish<true, 5>,
                           (const void *)k_order_keys<1>, (const void *)k_order_keys<2>, (const void *)k_order_keys<5>,
                           (const void *)k_trace, (const void *)k_trace_shadow, (const void *)k_trace_paths})
-        (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynamicLds);
     for (const void *k : {(const void *)k_rays<false, 1, BriefIO>, (const void *)k_rays<false, 2, BriefIO>, (const void *)k_rays<false, 5, BriefIO>,
                           (const void *)k_rays<false, 1, RayListWideIO>, (const void *)k_rays<false, 2, RayListWideIO>, (const void *)k_rays<false, 5, RayListWideIO>})
-        (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynamicLds);
     for (const void *k : {(const void *)k_photon_paths<false, 1>, (const void *)k_photon_paths<false, 2>, (const void *)k_photon_paths<false, 5>,
                           (const void *)k_photon_paths<true, 1>, (const void *)k_photon_paths<true, 2>, (const void *)k_photon_paths<true, 5>,
                           (const void *)k_photon_irradiance})
-        (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynamicLds);
+    (void)hipGetLastError(); // (a refused attribute must not show up as the error of a later launch)
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
     ctx->n_cu = prop.multiProcessorCount;
@@ -1079,7 +1089,11 @@ int rt_render(rt_ctx *ctx, const rt_render_params *prm, rt_frame_out *out)
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_halton.p, hal, sizeof hal, hipMemcpyHostToDevice, s));
 
     // pixel list of this shard in tile order (src/main.cpp:278-288), cached per image/tile geometry
-    const int key[5] = {W, H, prm->tile_size, prm->tile_rank, prm->tile_world};
+    // (RT_SPREAD: experiment - the wavefront pipeline's list dealt with a large stride, so that the pixels of one
+    // portion of the ray list come from far-apart places of the image)
+    static const int spread_env = getenv("RT_SPREAD") ? atoi(getenv("RT_SPREAD")) : 0;
+    const bool spread = spread_env != 0 && prm->mode == RT_MODE_PATH && prm->max_bounces > 0 && (ctx->pipeline == 1 || (ctx->pipeline < 0 && ctx->have_meshes));
+    const int key[6] = {W, H, prm->tile_size, prm->tile_rank, prm->tile_world, spread ? 1 : 0};
     if (memcmp(key, ctx->active_key, sizeof key) != 0) {
         const int ts = prm->tile_size;
         const int tx = (W + ts - 1) / ts, ty = (H + ts - 1) / ts;
@@ -1088,6 +1102,14 @@ int rt_render(rt_ctx *ctx, const rt_render_params *prm, rt_frame_out *out)
             const int x0 = (t % tx) * ts, y0 = (t / tx) * ts;
             const int tw = std::min(ts, W - x0), th = std::min(ts, H - y0);
             for (int j = y0; j < y0 + th; ++j) for (int i = x0; i < x0 + tw; ++i) ctx->active_host.push_back(j * W + i);
+        }
+        if (spread && ctx->active_host.size() > 64) {
+            const uint64_t n = ctx->active_host.size();
+            uint64_t stride = (uint64_t)((double)n * 0.3819660113) | 1u;
+            while (std::__gcd(stride, n) != 1) stride += 2;
+            std::vector<int32_t> dealt(n);
+            for (uint64_t i = 0; i < n; ++i) dealt[i] = ctx->active_host[(i * stride) % n];
+            ctx->active_host.swap(dealt);
         }
         // the shard's whole list stays on the device (8 MB at 1080p: a millisecond of upload per frame otherwise); the
         // first sampling round reads it, the later rounds' shrinking lists alternate between the two d_active buffers
@@ -1137,12 +1159,15 @@ int rt_render(rt_ctx *ctx, const rt_render_params *prm, rt_frame_out *out)
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters.p, 0, sizeof(DCounters), s));
 #ifdef RT_PROFILE_TAIL
     HIP_TRY(ctx, hipMemsetAsync((char *)ctx->d_counters.p + offsetof(DCounters, phase) + 12 * 8, 0xFF, 8, s)); // the minimum starts at the top
+    HIP_TRY(ctx, hipMemsetAsync((char *)ctx->d_counters.p + offsetof(DCounters, phase) + 0 * 8, 0xFF, 8, s));
+    HIP_TRY(ctx, hipMemsetAsync((char *)ctx->d_counters.p + offsetof(DCounters, phase) + 7 * 8, 0xFF, 8, s));
 #endif
     const bool gathers = prm->mode == RT_MODE_WHITTED && prm->photon_flags != 0;
     const size_t lds = gathers ? gather_lds_bytes(ctx->scene) : stack_lds_bytes(ctx->scene);
     double trace_ms = 0.0;
     uint32_t launches = 0;
     uint64_t wf_paths = 0; // camera paths of the wavefront pipeline (its kernels count rays only)
+    uint64_t wf_carried = 0;
     if (int rc = begin_cancellable(ctx)) return rc;
     ctx->prog_pixels_total.store(n0); ctx->prog_pixels_done.store(0); ctx->prog_round.store(0);
     ctx->prog_round_items.store(0); ctx->prog_round_done.store(0); ctx->prog_live_queue.store(0);
@@ -1157,7 +1182,8 @@ int rt_render(rt_ctx *ctx, const rt_render_params *prm, rt_frame_out *out)
     const int32_t *first_list = ctx->d_active_all.as<int32_t>();
     const bool order = ctx->order_pixels < 0 ? prm->tile_world > 1 : ctx->order_pixels != 0;
     const bool wavefront_frame = prm->mode == RT_MODE_PATH && prm->max_bounces > 0 && (ctx->pipeline == 1 || (ctx->pipeline < 0 && ctx->have_meshes));
-    if (order && prm->mode == RT_MODE_PATH && prm->max_bounces > 0 && n0 > 1 && !wavefront_frame) { // (the wavefront pipeline has all paths of a round in flight at once: nothing to order)
+    static const bool order_wave = getenv("RT_ORDER_WAVE") && atoi(getenv("RT_ORDER_WAVE")) != 0;
+    if ((order || (order_wave && wavefront_frame)) && prm->mode == RT_MODE_PATH && prm->max_bounces > 0 && n0 > 1 && (!wavefront_frame || order_wave)) { // (the wavefront pipeline has all paths of a round in flight at once: nothing to order)
         HIP_TRY(ctx, ctx->d_active_sorted.reserve(sizeof(int32_t) * n0));
         for (auto &b : ctx->d_keys) HIP_TRY(ctx, b.reserve(sizeof(uint32_t) * n0));
         const void *fn = ctx->ray_levels <= 1 ? (const void *)k_order_keys<1> : ctx->ray_levels == 2 ? (const void *)k_order_keys<2> : (const void *)k_order_keys<5>;
@@ -1235,7 +1261,7 @@ int rt_render(rt_ctx *ctx, const rt_render_params *prm, rt_frame_out *out)
                 void *args[] = {&a_scene, &F, &a_hal, &act, &a_items, &a_k0, &a_nk, &a_sbuf, &P, &a_ctr};
                 HIP_TRY(ctx, hipLaunchKernel(fn, grid, dim3(kBlock), args, lds, s));
             } else if (wavefront) {
-                if (int rc = render_wavefront(ctx, F, act, items, k0, nk, P, lds, &trace_ms, &launches)) return rc;
+                if (int rc = render_wavefront(ctx, F, act, items, k0, nk, P, lds, &trace_ms, &launches, &wf_carried)) return rc;
                 wf_paths += items;
             } else {
             // persistent launch: as many workgroups as the chip holds at once (more would only queue up)
@@ -1309,6 +1335,7 @@ int rt_render(rt_ctx *ctx, const rt_render_params *prm, rt_frame_out *out)
     c.gathers = dc.gathers; c.photon_visits = dc.photon_visits;
     for (int i = 0; i < 16; ++i) c.phase_cycles[i] = dc.phase[i];
     c.kernel_ms = ms; c.trace_kernel_ms = trace_ms; c.trace_launches = launches; c.trace_pipeline = wavefront ? 1u : 0u;
+    c.carried_rays = wf_carried;
     return RT_OK;
 }
 
