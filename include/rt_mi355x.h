@@ -242,7 +242,6 @@ typedef struct rt_counters {
     uint32_t trace_pipeline; /* after rt_render: 0 = lock-step kernel (one launch per sampling round), 1 = wavefront pipeline (one k_rays launch per bounce); after rt_trace_brief: 0 = the reference's binary BVH walk, 2 = the four-wide walk of the frames' rays (RT_QUERY_WIDE=1 in the environment at rt_init: a test gate) */
     uint64_t phase_cycles[16]; /* diagnostic builds only (RT_PROFILE_PHASES): per kernel phase wave clocks [0..3], executions [4..7], active lanes [8..11] */
     double bvh_build_ms;    /* GPU time the last rt_scene_upload spent building BVHs (0: the scene brought them) */
-    uint64_t carried_rays;  /* wavefront pipeline: extension rays a ray launch handed back unanswered near its end, traced again at the start of the next launch (counted once in closest_rays) */
 } rt_counters;
 
 /* ---- context ---- */

@@ -111,7 +111,7 @@ class Counters(C.Structure):
                 ("box_tests", C.c_uint64), ("tri_tests", C.c_uint64), ("gathers", C.c_uint64),
                 ("photon_visits", C.c_uint64), ("kernel_ms", C.c_double),
                 ("trace_kernel_ms", C.c_double), ("trace_launches", C.c_uint32), ("trace_pipeline", C.c_uint32),
-                ("phase_cycles", C.c_uint64 * 16), ("bvh_build_ms", C.c_double), ("carried_rays", C.c_uint64)]
+                ("phase_cycles", C.c_uint64 * 16), ("bvh_build_ms", C.c_double)]
 
 
 class ProgressInfo(C.Structure):

@@ -8,7 +8,7 @@
 //
 // Where rays come from and where answers go is a policy (IO): a plain list for the batch
 // query entry points (RayListIO, BriefIO below), the path state of the wavefront renderer (wavefront.h).
-//   bool fetch(e, o, d, any_hit, t_max, tag)   entry e of the list; false = no ray there.  tag is what
+//   bool fetch(e, split, o, d, any_hit, t_max, tag)   entry e of the list; false = no ray there.  tag is what
 //                                              the lane keeps of the entry (whatever the other calls need)
 //   void refetch(tag, any_hit, o, d)           the same ray again
 //   void put_closest(tag, t, node, face, front, u, v)   t = FLT_MAX, node = -1: nothing hit
@@ -16,13 +16,9 @@
 //   kDeferShadow, Pending, begin_put_shadow(tag, pending), end_put_shadow(tag, pending): an IO that has to read
 //   something before it can take the answer "not occluded" splits the hand-over into its loads and its stores; the
 //   kernel issues the loads, then the loads of the lane's next ray, and only then asks for the stores
-//   uint32_t setup(n)                          called once per thread before anything else: the length of the list (an IO
-//                                              whose lists have their lengths in device memory reads them here)
-//   kCarry, carried(tag), give_up(tag)         an IO that can take "not now" for an answer: near the end of a launch, when
-//                                              the list is empty and a wave is down to a few lanes, a closest-hit ray that
-//                                              is still walking is handed back unanswered, to be traced again in the next
-//                                              launch - a launch otherwise ends when its longest ray does, with the chip idle
-//                                              (carried(tag): this ray has been handed back once already, answer it)
+//   uint32_t setup(n, split)                   called once per thread before anything else: the length of the list (an IO
+//                                              whose lists have their lengths in device memory reads them here); split
+//                                              is a word the kernel keeps for the IO and hands to every fetch()
 #pragma once
 #include "kernels.h"
 
@@ -34,17 +30,14 @@ struct NoPending {};
 struct RayListIO {
     static constexpr bool kWide = false; // the reference's binary walk
     static constexpr bool kDeferShadow = false;
-    static constexpr bool kCarry = false;
     typedef NoPending Pending;
-    RT_DEV uint32_t setup(uint32_t n) { return n; }
-    RT_DEV bool carried(uint32_t) const { return true; }
-    RT_DEV void give_up(uint32_t) const {}
+    RT_DEV uint32_t setup(uint32_t n, uint32_t &) const { return n; }
     RT_DEV void begin_put_shadow(uint32_t, Pending &) const {}
     RT_DEV void end_put_shadow(uint32_t, const Pending &) const {}
     const float4 *ray_o, *ray_d;
     float4 *hit;
     float *hit_v;
-    RT_DEV bool fetch(uint32_t e, float4 &o, float4 &d, bool &any_hit, float &t_max, uint32_t &tag) const
+    RT_DEV bool fetch(uint32_t e, uint32_t, float4 &o, float4 &d, bool &any_hit, float &t_max, uint32_t &tag) const
     {
         o = ray_o[e]; d = ray_d[e];
         any_hit = !(o.w < 0.0f); t_max = o.w; tag = e;
@@ -71,11 +64,8 @@ struct RayListWideIO : RayListIO {
 struct BriefIO {
     static constexpr bool kWide = false;
     static constexpr bool kDeferShadow = false;
-    static constexpr bool kCarry = false;
     typedef NoPending Pending;
-    RT_DEV uint32_t setup(uint32_t n) { return n; }
-    RT_DEV bool carried(uint32_t) const { return true; }
-    RT_DEV void give_up(uint32_t) const {}
+    RT_DEV uint32_t setup(uint32_t n, uint32_t &) const { return n; }
     RT_DEV void begin_put_shadow(uint32_t, Pending &) const {}
     RT_DEV void end_put_shadow(uint32_t, const Pending &) const {}
     const float *rays6, *t_max; // t_max null: closest hits
@@ -85,7 +75,7 @@ struct BriefIO {
         const float *r = rays6 + (size_t)e * 6;
         o = make_float4(r[0], r[1], r[2], 0.0f); d = make_float4(r[3], r[4], r[5], 0.0f);
     }
-    RT_DEV bool fetch(uint32_t e, float4 &o, float4 &d, bool &any_hit, float &tm, uint32_t &tag) const
+    RT_DEV bool fetch(uint32_t e, uint32_t, float4 &o, float4 &d, bool &any_hit, float &tm, uint32_t &tag) const
     {
         any_hit = t_max != nullptr;
         tm = any_hit ? t_max[e] : -1.0f;
@@ -116,15 +106,6 @@ struct BriefIO {
 #ifndef RT_RAYS_REFILL_MIN_LANES
 #define RT_RAYS_REFILL_MIN_LANES 24 // fetch new rays once this many lanes are idle
 #endif
-// Handing rays back at the end of a launch (IO::kCarry): once the list is empty, a wave that has gone this many trips
-// further and is down to this many lanes hands its closest-hit rays back (0 lanes: never)
-#ifndef RT_CARRY_AFTER_TRIPS
-#define RT_CARRY_AFTER_TRIPS 32
-#endif
-#ifndef RT_CARRY_MAX_LANES
-#define RT_CARRY_MAX_LANES 8
-#endif
-
 // Records of the four-wide BVH kept in LDS by the ray-list kernel: the top levels of the scene's largest mesh, which
 // every ray of it passes (85 = three full levels; 0 builds the cache out)
 #ifndef RT_TOP4_RECORDS
@@ -435,15 +416,20 @@ RT_HD uint32_t ray_portion(uint64_t n_rays, unsigned grid_blocks)
 }
 
 // ray_chunk 0: sized here from the length of the list (ray_portion)
+// lane 0's value in every lane, as a scalar (the whole wave is active where this is called)
+RT_DEV uint32_t first_lane(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+RT_DEV unsigned long long first_lane(unsigned long long v)
+{
+    return ((unsigned long long)first_lane((uint32_t)(v >> 32)) << 32) | first_lane((uint32_t)v);
+}
+
 template <bool COUNT, int LEVELS, class IO>
-__global__ __launch_bounds__(kBlock, RT_RAYS_MIN_WAVES) void k_rays(DScene S, IO io_arg, uint32_t n_rays_arg, DCounters *ctr,
+__global__ __launch_bounds__(kBlock, RT_RAYS_MIN_WAVES) void k_rays(DScene S, IO io, uint32_t n_rays_arg, DCounters *ctr,
                                                                   unsigned long long *queue, uint32_t ray_chunk)
 {
-    IO io = io_arg;
-    const uint32_t n_rays = io.setup(n_rays_arg);
+    uint32_t list_split = 0;
+    const uint32_t n_rays = io.setup(n_rays_arg, list_split);
     if (ray_chunk == 0) ray_chunk = ray_portion(n_rays, gridDim.x);
-    constexpr bool kCarry = IO::kCarry && !COUNT && RT_CARRY_MAX_LANES > 0; // (a ray traced twice would count its box and triangle tests twice)
-    uint32_t late_trips = 0;
 #ifdef RT_PROFILE_TAIL
     // diagnostic build: when do the waves of one launch (the one launched with n_rays_arg == RT_PROFILE_TAIL) start,
     // run out of list, and end?  phase[0] earliest start, [1] latest end, [2] sum of starts, [3] sum of the moments the
@@ -492,14 +478,14 @@ __global__ __launch_bounds__(kBlock, RT_RAYS_MIN_WAVES) void k_rays(DScene S, IO
             {
                 unsigned long long old = 0;
                 if (lane == 0) old = atomicAdd(&s_win, (unsigned long long)want);
-                old = __shfl(old, 0, 64);
+                old = first_lane(old);
                 const uint32_t nx = (uint32_t)old, en = (uint32_t)(old >> 32);
                 if (nx < en) { first = nx; take = en - nx < want ? en - nx : want; }
                 else {
                     // the portion is used up: one wave fetches the next (the others come back at their next trip)
                     uint32_t got_lock = 0;
                     if (lane == 0) got_lock = (__hip_atomic_load(&s_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u && atomicCAS(&s_lock, 0u, 1u) == 0u) ? 1u : 0u;
-                    got_lock = __shfl(got_lock, 0, 64);
+                    got_lock = first_lane(got_lock);
                     if (got_lock) {
                         // (rt_cancel is not looked at here: a ray launch lasts milliseconds and the host checks between launches;
                         // reading the flag, which lives in host memory, at every draw cost the 1080p frame 13 ms)
@@ -522,17 +508,17 @@ __global__ __launch_bounds__(kBlock, RT_RAYS_MIN_WAVES) void k_rays(DScene S, IO
                             }
                             __hip_atomic_store(&s_lock, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                         }
-                        b = __shfl(b, 0, 64);
+                        b = first_lane(b);
                         first = (uint32_t)b; take = (uint32_t)(b >> 32);
                     }
                     if (take == 0) {
                         uint32_t done = 0;
                         if (lane == 0) done = __hip_atomic_load(&s_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (__shfl(done, 0, 64)) {
+                        if (first_lane(done)) {
                             // the list has run out - unless a last portion came in just before: look once more
                             unsigned long long now = 0;
                             if (lane == 0) now = __hip_atomic_load(&s_win, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            now = __shfl(now, 0, 64);
+                            now = first_lane(now);
                             if ((uint32_t)now >= (uint32_t)(now >> 32)) {
                                 exhausted = true;
 #ifdef RT_PROFILE_TAIL
@@ -553,7 +539,7 @@ __global__ __launch_bounds__(kBlock, RT_RAYS_MIN_WAVES) void k_rays(DScene S, IO
                 const uint32_t e = first + rank;
                 float4 o, d; bool shadow; float tmax; uint32_t tg;
                 const uint32_t old = w.tag;
-                const bool got = io.fetch(e, o, d, shadow, tmax, tg); // a list may have holes
+                const bool got = io.fetch(e, list_split, o, d, shadow, tmax, tg); // a list may have holes
                 if (owes) { io.end_put_shadow(old, pend); w.unoccluded = false; }
                 if (got) w.start(tg, o, d, shadow, tmax, pt);
             } else if (owes) { io.end_put_shadow(w.tag, pend); w.unoccluded = false; }
@@ -562,17 +548,6 @@ __global__ __launch_bounds__(kBlock, RT_RAYS_MIN_WAVES) void k_rays(DScene S, IO
         if (!__any(w.active)) {
             if (exhausted) break; // every wave gets here: the queue word only grows
             continue;
-        }
-        if (kCarry && exhausted && ++late_trips > (uint32_t)RT_CARRY_AFTER_TRIPS &&
-            (uint32_t)__popcll(__ballot(w.active)) <= (uint32_t)RT_CARRY_MAX_LANES) {
-            // the list is empty, the wave nearly so, and these rays have had their time: hand the closest-hit rays back
-            // unanswered (shadow rays are short and their answers are due in this launch: they stay)
-            if (w.active && !w.any_hit && !io.carried(w.tag)) {
-                io.give_up(w.tag);
-                --pt.closest; // counted when it is traced again
-                w.active = false; w.in_bvh = false; w.at_leaf = false; w.finished = false; w.cur = kNoNode; w.sp = 0;
-            }
-            if (!__any(w.active)) break;
         }
         w.phases(S, io, st, top4, pt, tl);
     }

@@ -47,51 +47,35 @@ struct WfState {
 struct WfCounts {
     uint32_t n_ext;    // extension rays: paths that go on from the previous bounce (bounce 0: the round's camera paths)
     uint32_t n_shadow; // shadow rays the previous bounce's shading left behind
-    uint32_t n_carry;  // extension rays the previous launch handed back unanswered (kPendingNode)
-    uint32_t pad;
+    uint32_t pad[2];
 };
-// In place of a node id in a path's hit record: "no answer yet".  Near the end of a ray launch, with the list empty and
-// the chip draining, a handful of long walks (grazing rays that cross hundreds of BVH nodes) would keep everything
-// waiting; they are handed back instead.  The shading launch passes such a path on to the next bounce's carried list
-// without touching it, the next ray launch traces it first of all (and to its end: kCarriedBit), and the path is
-// shaded one launch later than its neighbours - with the same inputs, so with the same result.
-constexpr int kPendingNode = (int)0x80000000;
-constexpr uint32_t kCarriedBit = 0x80000000u; // in a lane's tag: the ray comes from the carried list
 
-// ray list of k_rays: the carried extension rays first, then the extension rays of the slots the queue names (slot e
-// itself without a queue: the camera rays), then the shadow rays of the slots the shadow queue names
+// ray list of k_rays: the extension rays of the slots the queue names (slot e itself without a queue: the camera
+// rays), then the shadow rays of the slots the shadow queue names
 struct WfIO {
     static constexpr bool kWide = true; // four-wide BVH walk: the depth / id planes come from k_planes, not from these rays
     static constexpr bool kDeferShadow = true;
-    static constexpr bool kCarry = true;
     struct Pending { float4 c, a; };
     WfState P;
-    const uint32_t *queue, *carry, *sh_queue;
+    const uint32_t *queue, *sh_queue;
     const WfCounts *cnt;     // this bounce's list lengths
-    uint32_t shadows_only;   // leave the extension rays (carried ones too) alone: k_wf_finish takes them
-    uint32_t n_ext, n_carry; // set by setup()
-    RT_DEV uint32_t setup(uint32_t)
+    uint32_t shadows_only;   // leave the extension rays alone: k_wf_finish takes them
+    RT_DEV uint32_t setup(uint32_t, uint32_t &n_ext) const
     {
         n_ext = shadows_only ? 0u : cnt->n_ext;
-        n_carry = shadows_only ? 0u : cnt->n_carry;
-        return n_carry + n_ext + cnt->n_shadow;
+        return n_ext + cnt->n_shadow;
     }
-    RT_DEV bool carried(uint32_t tag) const { return (tag & kCarriedBit) != 0; }
-    RT_DEV void give_up(uint32_t tag) const { ((uint32_t *)&P.hit[tag & ~kCarriedBit])[1] = (uint32_t)kPendingNode; }
-    RT_DEV void refetch(uint32_t tag, bool any_hit, float4 &o, float4 &d) const
+    RT_DEV void refetch(uint32_t slot, bool any_hit, float4 &o, float4 &d) const
     {
-        const uint32_t slot = tag & ~kCarriedBit;
         if (any_hit) { o = P.sh_o[slot]; d = P.sh_d[slot]; }
         else { o = P.ray_o[slot]; d = P.ray_d[slot]; }
     }
     // the lane keeps the slot: every later access goes straight to the path's arrays
-    RT_DEV bool fetch(uint32_t e, float4 &o, float4 &d, bool &any_hit, float &t_max, uint32_t &tag) const
+    RT_DEV bool fetch(uint32_t e, uint32_t n_ext, float4 &o, float4 &d, bool &any_hit, float &t_max, uint32_t &slot) const
     {
-        any_hit = e >= n_carry + n_ext;
-        if (any_hit) tag = sh_queue[e - n_carry - n_ext];
-        else if (e < n_carry) tag = carry[e] | kCarriedBit;
-        else tag = queue ? queue[e - n_carry] : e - n_carry;
-        refetch(tag, any_hit, o, d);
+        any_hit = e >= n_ext;
+        slot = any_hit ? sh_queue[e - n_ext] : (queue ? queue[e] : e);
+        refetch(slot, any_hit, o, d);
         t_max = any_hit ? o.w : 0.0f;
         return true;
     }
@@ -101,9 +85,8 @@ struct WfIO {
     {
         P.acc[slot] = make_float4(p.a.x + p.c.x, p.a.y + p.c.y, p.a.z + p.c.z, p.a.w);
     }
-    RT_DEV void put_closest(uint32_t tag, float t, int node, uint32_t face, int front, float u, float v) const
+    RT_DEV void put_closest(uint32_t slot, float t, int node, uint32_t face, int front, float u, float v) const
     {
-        const uint32_t slot = tag & ~kCarriedBit;
         P.hit[slot] = make_float4(t, __uint_as_float((uint32_t)node), __uint_as_float(face | ((uint32_t)front << 31)), u);
         P.hit_v[slot] = v;
     }
@@ -121,7 +104,7 @@ struct WfIO {
 __global__ __launch_bounds__(kBlock) void k_wf_generate(DFrame F, const float *__restrict__ halton, const int32_t *__restrict__ active,
                                                         uint32_t n_items, int k0, int nk, WfState P, WfCounts *cnt0)
 {
-    if (blockIdx.x == 0 && threadIdx.x == 0) *cnt0 = WfCounts{n_items, 0u, 0u, 0u}; // the first bounce's lists (the rest of the array is zero)
+    if (blockIdx.x == 0 && threadIdx.x == 0) *cnt0 = WfCounts{n_items, 0u, {0u, 0u}}; // the first bounce's lists (the rest of the array is zero)
     for (uint32_t item = blockIdx.x * kBlock + threadIdx.x; item < n_items; item += gridDim.x * kBlock) {
         const uint32_t a = item / (uint32_t)nk;
         const int k = k0 + (int)(item - a * (uint32_t)nk);
@@ -207,7 +190,6 @@ RT_DEV bool surface_vertex(const DScene &S, const DFrame &F, const rt_light &lig
 struct LaneIO {
     static constexpr bool kWide = true;
     static constexpr bool kDeferShadow = true; // the kernel reads RayWalker::unoccluded itself
-    static constexpr bool kCarry = false;
     typedef NoPending Pending;
     Hit *h;
     RT_DEV void begin_put_shadow(uint32_t, Pending &) const {}
@@ -232,10 +214,10 @@ struct LaneIO {
 // fetches instead of two binary ones.  A pair whose path has ended takes the next one from the list.
 template <bool COUNT, int LEVELS>
 __global__ __launch_bounds__(kBlock) void k_wf_finish(DScene S, DFrame F, int k0, int nk, WfState P,
-                                                      const uint32_t *__restrict__ queue_in, const uint32_t *__restrict__ carry_in,
-                                                      const WfCounts *__restrict__ cnt, DCounters *ctr, unsigned long long *queue)
+                                                      const uint32_t *__restrict__ queue_in, const WfCounts *__restrict__ cnt,
+                                                      DCounters *ctr, unsigned long long *queue)
 {
-    const uint32_t n_carry = cnt->n_carry, n_in = n_carry + cnt->n_ext; // the carried paths, then the bounce's list
+    const uint32_t n_in = cnt->n_ext;
     extern __shared__ uint32_t lds[];
     const LaneStack st = lane_stack(lds, S);
     const rt_light &light = S.lights[0];
@@ -272,8 +254,7 @@ __global__ __launch_bounds__(kBlock) void k_wf_finish(DScene S, DFrame F, int k0
             const uint32_t rank = (uint32_t)__popcll(free_pairs & ((1ull << lane) - 1ull));
             if (b + want >= n_in) exhausted = true;
             if (keeper && !have_path && b + rank < n_in) {
-                const uint32_t e = (uint32_t)b + rank;
-                slot = e < n_carry ? carry_in[e] : queue_in[e - n_carry];
+                slot = queue_in[b + rank];
                 const float4 ro = P.ray_o[slot], rd = P.ray_d[slot], t = P.thr[slot], a = P.acc[slot];
                 const uint2 rs = P.rng[slot];
                 const int k = k0 + (int)(slot % (uint32_t)nk);
@@ -354,17 +335,15 @@ RT_DEV uint32_t lds_append(uint32_t *count, bool want)
     return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
 }
 
-// One bounce of every live path: the carried paths of the bounce, then its list.  FIRST: the camera rays' hits - the
-// list is implicit (slot e), the path state is its initial value and need not have been written.  Adds to *next the
-// paths that go on, the shadow rays, and the paths whose ray came back unanswered (passed on to carry_out untouched).
+// One bounce of every live path.  FIRST: the camera rays' hits - the list is implicit (slot e), the path state is
+// its initial value and need not have been written.  Adds to *next the paths that go on and the shadow rays.
 template <bool FIRST>
 __global__ __launch_bounds__(kBlock) void k_wf_shade(DScene S, DFrame F, const int32_t *__restrict__ active, int k0, int nk,
-                                                     WfState P, const uint32_t *__restrict__ queue_in, const uint32_t *__restrict__ carry_in,
+                                                     WfState P, const uint32_t *__restrict__ queue_in,
                                                      const WfCounts *__restrict__ cnt, uint32_t *__restrict__ queue_out,
-                                                     uint32_t *__restrict__ sh_queue_out, uint32_t *__restrict__ carry_out, WfCounts *next,
-                                                     FramePlanes out)
+                                                     uint32_t *__restrict__ sh_queue_out, WfCounts *next, FramePlanes out)
 {
-    const uint32_t n_carry = cnt->n_carry, n_in = n_carry + cnt->n_ext;
+    const uint32_t n_in = cnt->n_ext;
     uint32_t *const counts = &next->n_ext; // [0] paths that go on, [1] shadow rays
     __shared__ uint32_t s_ext[kShadeChunk], s_sh[kShadeChunk];
     __shared__ uint32_t s_order[kShadeChunk]; // the chunk's paths, those that hit the same thing next to each other
@@ -386,8 +365,7 @@ __global__ __launch_bounds__(kBlock) void k_wf_shade(DScene S, DFrame F, const i
 #pragma unroll
     for (uint32_t r = 0; r < kShadeRounds; ++r) {
         const uint32_t i = r * kBlock + threadIdx.x;
-        const uint32_t e = chunk_first + i;
-        my_slot[r] = i < chunk_n ? (e < n_carry ? carry_in[e] : (FIRST ? e - n_carry : queue_in[e - n_carry])) : 0u;
+        my_slot[r] = i < chunk_n ? (FIRST ? chunk_first + i : queue_in[chunk_first + i]) : 0u;
     }
 #pragma unroll
     for (uint32_t r = 0; r < kShadeRounds; ++r) {
@@ -444,20 +422,7 @@ __global__ __launch_bounds__(kBlock) void k_wf_shade(DScene S, DFrame F, const i
             const bool hit = h.node != -1;
             V3 add = mk(0.0f, 0.0f, 0.0f);
             bool adds = false;
-            if (h.node == kPendingNode) { // no answer yet: on to the next launch's carried list, as it is
-                const uint64_t m = __ballot(true);
-                const uint32_t lane = threadIdx.x & 63u, leader = (uint32_t)__ffsll((unsigned long long)m) - 1u;
-                uint32_t base = 0;
-                if (lane == leader) base = atomicAdd(&next->n_carry, (uint32_t)__popcll(m));
-                base = __shfl(base, (int)leader, 64);
-                carry_out[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = slot;
-                if (FIRST) { // what k_wf_shade<false> will read of a path that has not been shaded yet
-                    Rng rng;
-                    rng_set_sequence(rng, (uint64_t)k + 1, pixel_seed(F.seed, (uint64_t)active[a]));
-                    P.thr[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-                    P.rng[slot] = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
-                }
-            } else if (!hit) { // main.cpp:175-176
+            if (!hit) { // main.cpp:175-176
                 add = textured_color(S, S.background, S.background_texture, ray.d) * thr;
                 adds = true;
             } else if (h.node < 0) { // light (main.cpp:184-210)
@@ -519,7 +484,7 @@ __global__ __launch_bounds__(kBlock) void k_wf_shade(DScene S, DFrame F, const i
                     want_ext = true;
                 }
             }
-            if (FIRST) { add = mk(0.0f, 0.0f, 0.0f) + add; P.acc[slot] = make_float4(add.x, add.y, add.z, 0.0f); } // the accumulator starts here (with zero for a path passed on unanswered)
+            if (FIRST) { add = mk(0.0f, 0.0f, 0.0f) + add; P.acc[slot] = make_float4(add.x, add.y, add.z, 0.0f); } // the accumulator starts here
             else if (adds) {
                 float4 acc = P.acc[slot];
                 acc.x = acc.x + add.x; acc.y = acc.y + add.y; acc.z = acc.z + add.z;

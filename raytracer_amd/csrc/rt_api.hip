@@ -81,7 +81,15 @@ struct rt_ctx {
     int order_pixels = -1;    // RT_ORDER: 1 = always deal a frame's pixels expensive-first, 0 = never (tile order), default: for tile shards only
     DeviceBuf d_stack_ovf;
     // wavefront pipeline (device/wavefront.h): per-slot path state, the bounce lists, list counts, event pairs around the ray launches
-    DeviceBuf d_wf_state, d_wf_queue[2], d_wf_carry[2], d_wf_sh_queue, d_wf_counts;
+    DeviceBuf d_wf_state, d_wf_queue[2], d_wf_sh_queue, d_wf_counts;
+    // The list lengths a round went through, by what the round was (frame constants, items, samples, scene): a round
+    // that comes again (the next frame of the same view) is launched from them without the host waiting for the device
+    // after every bounce; the lengths the device then reports are compared with them afterwards.
+    struct WfProfile { uint64_t key = 0; std::vector<WfCounts> counts; };
+    std::vector<WfProfile> wf_profiles; // a handful, oldest replaced first
+    size_t wf_profile_next = 0;
+    uint64_t scene_generation = 0;
+    bool wf_replay = true;              // RT_WF_REPLAY=0: always wait for the device's counts
     static constexpr int kMaxRayLaunches = 96;
     hipEvent_t ray_ev[2 * kMaxRayLaunches] = {};
     uint32_t finish_below = 0; // RT_FINISH_BELOW: paths left in a round at which the wavefront pipeline hands over to k_wf_finish (default: 512 per CU; measured 8 k / 32 k / 128 k / 512 k: 101.3 / 99.8 / 98.3 / 99.2 ms per 1080p frame, 20.3 / 19.3 / 17.9 / 19.1 ms on an eighth of it)
@@ -274,12 +282,11 @@ size_t gather_lds_bytes(const DScene &S) { return stack_lds_bytes(S) + kHeapLdsB
 } // namespace
 
 // One sampling round of `items` camera paths through the wavefront pipeline (device/wavefront.h): camera rays, then per
-// bounce one ray launch (extension rays handed back by the previous launch, extension rays of the live paths, shadow
-// rays of the previous bounce) and one shading launch, until no path and no shadow ray is left.  The lists' lengths stay
+// bounce one ray launch (extension rays of the live paths, shadow rays of the previous bounce) and one shading launch, until no path and no shadow ray is left.  The lists' lengths stay
 // in device memory, one WfCounts per bounce, where the kernels read them; the host reads them too, after every shading
 // launch, to size the next launches and to see when to hand over to k_wf_finish.
 static int render_wavefront(rt_ctx *ctx, const DFrame &F, const int32_t *act, uint64_t items64, int k0, int nk,
-                            const FramePlanes &planes, size_t lds, double *ray_ms, uint32_t *ray_launches, uint64_t *carried)
+                            const FramePlanes &planes, size_t lds, double *ray_ms, uint32_t *ray_launches)
 {
     hipStream_t s = ctx->stream;
     const uint32_t items = (uint32_t)items64;
@@ -289,10 +296,8 @@ static int render_wavefront(rt_ctx *ctx, const DFrame &F, const int32_t *act, ui
     for (int i = 0; i < 9; ++i) { offs[i] = total; total += ((size_t)items * sizes[i] + 255) / 256 * 256; }
     HIP_TRY(ctx, ctx->d_wf_state.reserve(total));
     for (auto &q : ctx->d_wf_queue) HIP_TRY(ctx, q.reserve((size_t)items * 4));
-    for (auto &q : ctx->d_wf_carry) HIP_TRY(ctx, q.reserve((size_t)items * 4));
     HIP_TRY(ctx, ctx->d_wf_sh_queue.reserve((size_t)items * 4));
-    // a path falls behind its bounce number by one launch each time its ray is handed back, at most once per bounce
-    const int n_entries = 2 * F.max_bounces + 8;
+    const int n_entries = F.max_bounces + 4;
     HIP_TRY(ctx, ctx->d_wf_counts.reserve((size_t)n_entries * sizeof(WfCounts)));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_wf_counts.p, 0, (size_t)n_entries * sizeof(WfCounts), s));
     WfCounts *const cnt = ctx->d_wf_counts.as<WfCounts>();
@@ -332,7 +337,7 @@ static int render_wavefront(rt_ctx *ctx, const DFrame &F, const int32_t *act, ui
     // one ray launch over the lists of bounce b (n_rays: what the host knows of their total length, for the grid)
     const auto launch_rays = [&](int b, const uint32_t *queue_in, uint64_t n_rays, bool shadows_only) -> int {
         const dim3 grid((unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_rays + kBlock - 1) / kBlock, (uint64_t)ctx->n_cu * per_cu)));
-        WfIO a_io{P, queue_in, ctx->d_wf_carry[b & 1].as<uint32_t>(), sh_queue, cnt + b, shadows_only ? 1u : 0u, 0u, 0u};
+        WfIO a_io{P, queue_in, sh_queue, cnt + b, shadows_only ? 1u : 0u};
         uint32_t a_n = (uint32_t)b, a_chunk = 0; // the kernel takes the list's length from cnt[b] and sizes the portions itself (the bounce number only serves diagnostic builds)
         void *targs[] = {&a_scene, &a_io, &a_n, &a_ctr, &a_queue, &a_chunk};
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue.p, 0, kQueueBytes, s));
@@ -343,12 +348,32 @@ static int render_wavefront(rt_ctx *ctx, const DFrame &F, const int32_t *act, ui
         return RT_OK;
     };
 
-    WfCounts h{items, 0u, 0u, 0u}; // the host's copy of cnt[b]
+    // what this round is, as far as its list lengths go
+    uint64_t key = 1469598103934665603ull;
+    const auto mix = [&](const void *p, size_t n) { for (size_t i = 0; i < n; ++i) key = (key ^ ((const unsigned char *)p)[i]) * 1099511628211ull; };
+    mix(&F, sizeof F); mix(&items, sizeof items); mix(&k0, sizeof k0); mix(&nk, sizeof nk); mix(&act, sizeof act);
+    mix(&ctx->scene_generation, sizeof ctx->scene_generation); mix(&ctx->finish_below, sizeof ctx->finish_below);
+    mix(ctx->active_key, sizeof ctx->active_key); // which pixels: image size, tiles, shard
+    const rt_ctx::WfProfile *known = nullptr;
+    if (ctx->wf_replay) for (const auto &pr : ctx->wf_profiles) if (pr.key == key) known = &pr;
+    std::vector<WfCounts> seen; // cnt[0..] as the host learns them (or takes them from the profile)
+    static const bool wf_debug = getenv("RT_WF_DEBUG") != nullptr;
+    if (wf_debug) fprintf(stderr, "wavefront round: key %016llx %s\n", (unsigned long long)key, known ? "replayed from its profile" : "new");
+
+    for (int attempt = 0; attempt < 2; ++attempt) {
+    const bool replay = known != nullptr;
+    seen.assign(1, WfCounts{items, 0u, {0u, 0u}});
+    if (attempt > 0) { // the device's lists were not what the profile said: once more, waiting for every bounce's counts
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_wf_counts.p, 0, (size_t)n_entries * sizeof(WfCounts), s));
+        hipLaunchKernelGGL(k_wf_generate, wide, dim3(kBlock), 0, s, F, ctx->d_halton.as<float>(), act, items, k0, nk, P, cnt);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    WfCounts h = seen[0]; // the host's idea of cnt[b]
     bool finishing = false;
     int cur = 0;
     const uint32_t *queue_in = nullptr; // the camera rays: slot e
     for (int b = 0;; ++b) {
-        const uint64_t n_live = (uint64_t)h.n_ext + h.n_carry;
+        const uint64_t n_live = h.n_ext;
         if (finishing) { // the shadow rays of the last shaded bounce, then the remaining paths to their ends in one launch
             if (h.n_shadow > 0) if (int rc = launch_rays(b, queue_in, h.n_shadow, true)) return rc;
             const void *ff = ctx->counting ? (ctx->ray_levels <= 1 ? (const void *)k_wf_finish<true, 1> : ctx->ray_levels == 2 ? (const void *)k_wf_finish<true, 2> : (const void *)k_wf_finish<true, 5>)
@@ -357,12 +382,10 @@ static int render_wavefront(rt_ctx *ctx, const DFrame &F, const int32_t *act, ui
             const dim3 grid((unsigned)std::min<uint64_t>((n_live * 2 + kBlock - 1) / kBlock, ctx->ovf_threads / kBlock));
             DFrame f_frame = F;
             int f_k0 = k0, f_nk = nk;
-            const uint32_t *f_carry = ctx->d_wf_carry[b & 1].as<uint32_t>();
             const WfCounts *f_cnt = cnt + b;
             HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue.p, 0, kQueueBytes, s));
-            void *fargs[] = {&a_scene, &f_frame, &f_k0, &f_nk, &P, &queue_in, &f_carry, &f_cnt, &a_ctr, &a_queue};
+            void *fargs[] = {&a_scene, &f_frame, &f_k0, &f_nk, &P, &queue_in, &f_cnt, &a_ctr, &a_queue};
             HIP_TRY(ctx, hipLaunchKernel(ff, grid, dim3(kBlock), fargs, lds, s));
-            ctx->prog_round_done.store(items);
             break;
         }
         if (n_live + h.n_shadow == 0) break;
@@ -371,28 +394,50 @@ static int render_wavefront(rt_ctx *ctx, const DFrame &F, const int32_t *act, ui
         {
             const dim3 grid((unsigned)std::min<uint64_t>((n_live + kShadeChunk - 1) / kShadeChunk, (uint64_t)ctx->n_cu * 16));
             uint32_t *queue_out = ctx->d_wf_queue[cur].as<uint32_t>();
-            const uint32_t *carry_in = ctx->d_wf_carry[b & 1].as<uint32_t>();
-            uint32_t *carry_out = ctx->d_wf_carry[(b + 1) & 1].as<uint32_t>();
-            if (b == 0) hipLaunchKernelGGL(k_wf_shade<true>, grid, dim3(kBlock), 0, s, a_scene, F, act, k0, nk, P, queue_in, carry_in, cnt + b, queue_out, sh_queue, carry_out, cnt + b + 1, planes);
-            else hipLaunchKernelGGL(k_wf_shade<false>, grid, dim3(kBlock), 0, s, a_scene, F, act, k0, nk, P, queue_in, carry_in, cnt + b, queue_out, sh_queue, carry_out, cnt + b + 1, planes);
+            if (b == 0) hipLaunchKernelGGL(k_wf_shade<true>, grid, dim3(kBlock), 0, s, a_scene, F, act, k0, nk, P, queue_in, cnt + b, queue_out, sh_queue, cnt + b + 1, planes);
+            else hipLaunchKernelGGL(k_wf_shade<false>, grid, dim3(kBlock), 0, s, a_scene, F, act, k0, nk, P, queue_in, cnt + b, queue_out, sh_queue, cnt + b + 1, planes);
             HIP_TRY(ctx, hipGetLastError());
             queue_in = queue_out;
             cur ^= 1;
         }
-        // the next bounce's list lengths, into pinned memory (a pageable destination goes through a staging copy)
-        volatile uint32_t *got = (volatile uint32_t *)&ctx->host_words[2];
-        HIP_TRY(ctx, hipMemcpyAsync((void *)got, cnt + b + 1, sizeof(WfCounts), hipMemcpyDeviceToHost, s));
-        HIP_TRY(ctx, hipStreamSynchronize(s));
-        h = WfCounts{got[0], got[1], got[2], 0u};
-        *carried += h.n_carry;
-        const uint64_t left = (uint64_t)h.n_ext + h.n_carry;
-        ctx->prog_round_done.store(items - std::min<uint64_t>(items, left)); // paths that have ended
-        // few paths left: their shadow rays next (a ray launch without extension rays), then k_wf_finish; the same when
-        // the array of list lengths is about to run out (paths handed back over and over: the finisher takes them all)
-        if (left > 0 && (left <= ctx->finish_below || b + 3 >= n_entries)) finishing = true;
-        if (cancelled(ctx)) break; // the round's kernels hand out no more rays; rt_render reports the cancellation
+        if (replay && (size_t)b + 1 < known->counts.size()) h = known->counts[b + 1];
+        else if (replay) h = WfCounts{0u, 0u, {0u, 0u}}; // (the profile ends here; the check below tells if the device's lists do too)
+        else {
+            // the next bounce's list lengths, into pinned memory (a pageable destination goes through a staging copy)
+            volatile uint32_t *got = (volatile uint32_t *)&ctx->host_words[2];
+            HIP_TRY(ctx, hipMemcpyAsync((void *)got, cnt + b + 1, sizeof(WfCounts), hipMemcpyDeviceToHost, s));
+            HIP_TRY(ctx, hipStreamSynchronize(s));
+            h = WfCounts{got[0], got[1], {0u, 0u}};
+            ctx->prog_round_done.store(items - std::min<uint64_t>(items, h.n_ext)); // paths that have ended
+            if (cancelled(ctx)) break; // the round's kernels hand out no more rays; rt_render reports the cancellation
+        }
+        seen.push_back(h);
+        // few paths left: their shadow rays next (a ray launch without extension rays), then k_wf_finish
+        if (h.n_ext > 0 && (h.n_ext <= ctx->finish_below || b + 3 >= n_entries)) finishing = true;
+    }
+    if (!replay) break;
+    // launched from the profile: are the device's list lengths the profile's?  (They are, for the same frame again: a
+    // path's fate does not depend on when it is traced.  A frame that only looks the same is done again.)
+    std::vector<WfCounts> dev(seen.size() + 1);
+    HIP_TRY(ctx, hipMemcpyAsync(dev.data(), cnt, std::min(dev.size(), (size_t)n_entries) * sizeof(WfCounts), hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    bool same = true;
+    for (size_t i = 0; i < seen.size(); ++i) same = same && dev[i].n_ext == seen[i].n_ext && dev[i].n_shadow == seen[i].n_shadow;
+    if (same) break;
+    if (wf_debug) fprintf(stderr, "wavefront round: the profile did not hold, once more\n");
+    known = nullptr;
+    launch = 0;
     }
     HIP_TRY(ctx, hipStreamSynchronize(s));
+    ctx->prog_round_done.store(items);
+    if (!known && !cancelled(ctx) && ctx->wf_replay) { // remember what this round went through
+        constexpr size_t kProfiles = 32;
+        rt_ctx::WfProfile *pr = nullptr;
+        for (auto &have : ctx->wf_profiles) if (have.key == key) pr = &have; // (one that did not hold: replaced)
+        if (!pr && ctx->wf_profiles.size() < kProfiles) { ctx->wf_profiles.emplace_back(); pr = &ctx->wf_profiles.back(); }
+        if (!pr) { pr = &ctx->wf_profiles[ctx->wf_profile_next]; ctx->wf_profile_next = (ctx->wf_profile_next + 1) % kProfiles; }
+        pr->key = key; pr->counts = seen;
+    }
     for (int i = 0; i < launch; ++i) {
         float ms = 0;
         HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ray_ev[2 * i], ctx->ray_ev[2 * i + 1]));
@@ -493,6 +538,7 @@ int rt_init(int device, rt_ctx **out)
     if (const char *e7 = getenv("RT_ORDER")) ctx->order_pixels = atoi(e7) != 0 ? 1 : 0;
     if (const char *e11 = getenv("RT_GPU_BVH")) ctx->gpu_bvh = atoi(e11) != 0;
     if (const char *e12 = getenv("RT_QUERY_WIDE")) ctx->query_wide = atoi(e12) != 0;
+    if (const char *e13 = getenv("RT_WF_REPLAY")) ctx->wf_replay = atoi(e13) != 0;
     if (const char *e10 = getenv("RT_TLAS_MIN")) ctx->tlas_min_objects = std::max(0, atoi(e10));
     if (const char *e2 = getenv("RT_LDS_LEVELS")) ctx->lds_levels_max = std::max(1, std::min(64, atoi(e2))); // tuning knob
     if ((e = ctx->d_queue.reserve(kQueueBytes)) != hipSuccess) return bail("hipMalloc", e);
@@ -1042,6 +1088,7 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc)
     ctx->pmap_n[0] = ctx->pmap_n[1] = 0; // photon maps belong to the scene they were traced in
     ctx->pmap_flags = -1;
     ctx->scene = S;
+    ++ctx->scene_generation;
     ctx->ray_levels = ray_levels;
     ctx->have_meshes = max_mesh_depth >= 0;
     ctx->have_scene = true;
@@ -1167,7 +1214,6 @@ int rt_render(rt_ctx *ctx, const rt_render_params *prm, rt_frame_out *out)
     double trace_ms = 0.0;
     uint32_t launches = 0;
     uint64_t wf_paths = 0; // camera paths of the wavefront pipeline (its kernels count rays only)
-    uint64_t wf_carried = 0;
     if (int rc = begin_cancellable(ctx)) return rc;
     ctx->prog_pixels_total.store(n0); ctx->prog_pixels_done.store(0); ctx->prog_round.store(0);
     ctx->prog_round_items.store(0); ctx->prog_round_done.store(0); ctx->prog_live_queue.store(0);
@@ -1261,7 +1307,7 @@ int rt_render(rt_ctx *ctx, const rt_render_params *prm, rt_frame_out *out)
                 void *args[] = {&a_scene, &F, &a_hal, &act, &a_items, &a_k0, &a_nk, &a_sbuf, &P, &a_ctr};
                 HIP_TRY(ctx, hipLaunchKernel(fn, grid, dim3(kBlock), args, lds, s));
             } else if (wavefront) {
-                if (int rc = render_wavefront(ctx, F, act, items, k0, nk, P, lds, &trace_ms, &launches, &wf_carried)) return rc;
+                if (int rc = render_wavefront(ctx, F, act, items, k0, nk, P, lds, &trace_ms, &launches)) return rc;
                 wf_paths += items;
             } else {
             // persistent launch: as many workgroups as the chip holds at once (more would only queue up)
@@ -1335,7 +1381,6 @@ int rt_render(rt_ctx *ctx, const rt_render_params *prm, rt_frame_out *out)
     c.gathers = dc.gathers; c.photon_visits = dc.photon_visits;
     for (int i = 0; i < 16; ++i) c.phase_cycles[i] = dc.phase[i];
     c.kernel_ms = ms; c.trace_kernel_ms = trace_ms; c.trace_launches = launches; c.trace_pipeline = wavefront ? 1u : 0u;
-    c.carried_rays = wf_carried;
     return RT_OK;
 }
 

@@ -381,6 +381,38 @@ def test_pipelines_agree(monkeypatch):
             c.close()
 
 
+def test_a_frame_launched_from_its_profile_is_the_same_frame(monkeypatch):
+    """The wavefront pipeline launches a round it has seen before (same view, same samples) from the list lengths it
+    recorded then, without waiting for the device after every bounce: the second and third rendering of a frame must
+    equal the first bit for bit, equal a context that never does this (RT_WF_REPLAY=0), and a frame that differs
+    (another seed: other list lengths) must come out right after them - adaptive rounds and tile shards included."""
+    monkeypatch.setenv("RT_PIPELINE", "wave")
+    fast = lib.Context(0)
+    monkeypatch.setenv("RT_WF_REPLAY", "0")
+    plain = lib.Context(0)
+    monkeypatch.delenv("RT_WF_REPLAY")
+    monkeypatch.delenv("RT_PIPELINE")
+    try:
+        s = O.scene_from_golden(O.load_golden("scene_mesh"))
+        w, h = 160, 90
+        for c in (fast, plain):
+            c.upload(s.desc)
+            c.set_camera(s.camera, w, h)
+        for kw in (dict(seed=5, min_spp=3, max_spp=20, delta_max=0.02), dict(seed=5, min_spp=4, max_spp=4, tile_rank=1, tile_world=3),
+                   dict(seed=6, min_spp=3, max_spp=20, delta_max=0.02), dict(seed=5, min_spp=3, max_spp=20, delta_max=0.02)):
+            want = plain.render(abi.default_params(**kw))
+            for again in range(3):
+                got = fast.render(abi.default_params(**kw))
+                for plane in ("rgb", "z", "sample_count", "object_id"):
+                    assert np.array_equal(getattr(got, plane), getattr(want, plane)), (kw, again, plane)
+                assert np.array_equal(bits(got.linear), bits(want.linear)), (kw, again)
+                k, kp = fast.counters(), plain.counters()
+                assert (k.closest_rays, k.shadow_rays, k.camera_paths) == (kp.closest_rays, kp.shadow_rays, kp.camera_paths)
+    finally:
+        fast.close()
+        plain.close()
+
+
 def test_pixel_order_does_not_change_the_frame(monkeypatch):
     """Dealing a frame's pixels expensive-first (scheduling keys from one camera ray per pixel + radix sort; the
     default for tile shards) only changes when a pixel is rendered: every plane, the adaptive sample counts and
