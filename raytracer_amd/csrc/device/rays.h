@@ -310,10 +310,15 @@ template <bool COUNT, int LEVELS, class IO> struct RayWalker {
                         a0 = rec[0]; a1 = rec[1]; b0 = rec[2]; b1 = rec[3]; c0 = rec[4]; c1 = rec[5]; e0 = rec[6]; e1 = rec[7];
                     }
                     float d0, d1, d2, d3;
-                    const bool h0 = bvh_box(exact, lr.p, inv, t_limit, a0, a1, d0) && d0 < t_limit;
-                    const bool h1 = bvh_box(exact, lr.p, inv, t_limit, b0, b1, d1) && d1 < t_limit;
-                    const bool h2 = bvh_box(exact, lr.p, inv, t_limit, c0, c1, d2) && d2 < t_limit;
-                    const bool h3 = bvh_box(exact, lr.p, inv, t_limit, e0, e1, d3) && d3 < t_limit;
+                    bool h0, h1, h2, h3;
+                    if (__builtin_expect(exact, 0)) { // (one branch around the four tests, not one in each)
+                        h0 = bvh_box_exact(lr.p, inv, t_limit, a0, a1, d0); h1 = bvh_box_exact(lr.p, inv, t_limit, b0, b1, d1);
+                        h2 = bvh_box_exact(lr.p, inv, t_limit, c0, c1, d2); h3 = bvh_box_exact(lr.p, inv, t_limit, e0, e1, d3);
+                    } else {
+                        h0 = bvh_box_fast(lr.p, inv, t_limit, a0, a1, d0); h1 = bvh_box_fast(lr.p, inv, t_limit, b0, b1, d1);
+                        h2 = bvh_box_fast(lr.p, inv, t_limit, c0, c1, d2); h3 = bvh_box_fast(lr.p, inv, t_limit, e0, e1, d3);
+                    }
+                    h0 = h0 && d0 < t_limit; h1 = h1 && d1 < t_limit; h2 = h2 && d2 < t_limit; h3 = h3 && d3 < t_limit;
                     uint32_t k0 = __float_as_uint(a1.z), k1 = __float_as_uint(b1.z), k2 = __float_as_uint(c1.z), k3 = __float_as_uint(e1.z);
                     // boxes the ray does not enter sort to the end
                     d0 = h0 && k0 != kNoNode ? d0 : INFINITY; d1 = h1 && k1 != kNoNode ? d1 : INFINITY;
