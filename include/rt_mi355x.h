@@ -322,6 +322,35 @@ int rt_trace_brief(rt_ctx *ctx, const float *rays6, const float *t_max, int n, r
 #define RT_NOALLOC_MAX_RAYS (1 << 24)
 int rt_trace_brief_noalloc(rt_ctx *ctx, const float *d_rays6, const float *d_t_max, int n, rt_hit_brief *d_out);
 
+/* ---- known-answer queries for tests: the samplers and random streams the kernels use, one evaluation per query, so
+ * that fixtures made from the reference's own samplers can be compared with the device code value for value.
+ *   RT_SAMPLER_LIGHT            PointLight::GenerateSample at p and GetSampleInfo for `dir` (src/lights.h:208-288), lights[0]
+ *   RT_SAMPLER_MATERIAL         MtlBlinn::GenerateSample and GetSampleInfo for `dir` (src/materials.h:87-303)
+ *   RT_SAMPLER_PHOTON_MATERIAL  MtlBlinn::GenerateSample of the project-12 snapshot, which scatters photons (project12.zip src/materials.h:82-193)
+ *   RT_SAMPLER_PHOTON_EMIT      PointLight::RandomPhoton (src/lights.h:92-124): origin, dir, mult = the photon's colour
+ * Every query draws from PCG stream (seq, seed) (RNG::SetSequence, src/rng.h:39-46); next_u32 is the stream's next
+ * number after the call, which pins how many it drew.  Host pointers. ---- */
+enum { RT_SAMPLER_LIGHT = 0, RT_SAMPLER_MATERIAL = 1, RT_SAMPLER_PHOTON_MATERIAL = 2, RT_SAMPLER_PHOTON_EMIT = 3 };
+typedef struct rt_sampler_query {
+    float p[3], n[3], v[3]; /* surface point, unit shading normal, unit direction towards the viewer */
+    int32_t front;
+    float dir[3];           /* direction whose probability GetSampleInfo is asked for */
+    int32_t material;
+    uint64_t seq, seed;
+} rt_sampler_query;
+typedef struct rt_sampler_answer {
+    float dir[3], mult[3], prob, dist;
+    int32_t ok, lobe;       /* GenerateSample's return value and lobe */
+    float pdf;              /* GetSampleInfo(dir).prob */
+    uint32_t next_u32;
+    float origin[3];        /* RT_SAMPLER_PHOTON_EMIT: where the photon starts */
+    float pad;
+} rt_sampler_answer;
+int rt_debug_samplers(rt_ctx *ctx, int which, const rt_sampler_query *queries, int n, rt_sampler_answer *out);
+/* n_draws numbers of each of n_streams PCG streams: RNG::RandomUInt (words) and, from the stream seeded again,
+ * RNG::RandomFloat (floats) (src/rng.h:48-65); both arrays are [n_streams][n_draws].  Needs no scene. */
+int rt_debug_rng(rt_ctx *ctx, const uint64_t *seq, const uint64_t *seed, int n_streams, int n_draws, uint32_t *words, float *floats);
+
 /* ---- photon maps: replaces class PhotonMap (src/photonmap.h:38-414) and the emission loops of the
  * project-12 snapshot's main() (project12.zip src/main.cpp:262-470) ---- */
 

@@ -718,7 +718,7 @@ int orc_mtl_generate(const rt_material *m, const orc_surface *s, orc_rng *rng, o
     const v3 kd = vld(m->diffuse), ks = vld(m->specular), kt = vld(m->refraction);
     float pd, ps, pt;
     lobe_probs(m, &pd, &ps, &pt);
-    const float fresnelRatio = powf((1.0f - m->ior) / (1.0f + m->ior), 2.0f);
+    const float schlick = powf((1.0f - m->ior) / (1.0f + m->ior), 2.0f);
     const v3 Ns = vld(s->n), V = vld(s->v);
     o->dist = 0.0f;
     const float rnd = orc_rng_float(rng);
@@ -751,20 +751,20 @@ int orc_mtl_generate(const rt_material *m, const orc_surface *s, orc_rng *rng, o
         const v3 h = vadd(vadd(vscale(u, x), vscale(v, y)), vscale(Ns, cosT));
         const v3 dir = vnormalize(vsub(vscale(vscale(h, 2.0f), std_max(0.0f, vdot(V, h))), V));
         vst(o->dir, dir);
-        const float nDotH = vdot(Ns, h);
-        if (nDotH < 0.0f) return 0;
-        const float pdfH = ((alpha + 1.0f) / (8.0f * PI_F)) * powf(cosT, alpha);
-        o->prob = (pdfH / (4.0f * vdot(V, h))) * ps;
-        const float specNorm = (alpha + 2.0f) / (8.0f * PI_F);
-        vst(o->mult, vdivs(vscale(vscale(ks, specNorm), powf(nDotH, alpha)), (4.0f * vdot(V, h))));
+        const float cos_nh = vdot(Ns, h);
+        if (cos_nh < 0.0f) return 0;
+        const float half_pdf = ((alpha + 1.0f) / (8.0f * PI_F)) * powf(cosT, alpha);
+        o->prob = (half_pdf / (4.0f * vdot(V, h))) * ps;
+        const float lobe_scale = (alpha + 2.0f) / (8.0f * PI_F);
+        vst(o->mult, vdivs(vscale(vscale(ks, lobe_scale), powf(cos_nh, alpha)), (4.0f * vdot(V, h))));
         return 1;
     }
     if (rnd < pd + ps + pt) {
         o->lobe = LOBE_TRANSMISSION;
         v3 N = Ns;
-        float etaI = 1.0f, etaT = m->ior;
-        if (!s->front) { N = vneg(N); float t = etaI; etaI = etaT; etaT = t; }
-        const float eta = etaI / etaT;
+        float n_from = 1.0f, n_into = m->ior;
+        if (!s->front) { N = vneg(N); float t = n_from; n_from = n_into; n_into = t; }
+        const float eta = n_from / n_into;
         const float alpha = m->glossiness;
         const float phi = 2.0f * PI_F * orc_rng_float(rng);
         const float cosT = powf(1.0f - orc_rng_float(rng), 1.0f / (alpha + 1.0f));
@@ -774,19 +774,19 @@ int orc_mtl_generate(const rt_material *m, const orc_surface *s, orc_rng *rng, o
         v3 u, v;
         orthonormals(N, &u, &v);
         const v3 h = vadd(vadd(vscale(u, x), vscale(v, y)), vscale(N, cosT));
-        const float vDotH = vdot(V, h);
-        const float k = 1.0f - eta * eta * (1.0f - vDotH * vDotH);
+        const float cos_vh = vdot(V, h);
+        const float k = 1.0f - eta * eta * (1.0f - cos_vh * cos_vh);
         vst(o->mult, kt);
         o->prob = pt;
         if (k < 0.0f) {
             vst(o->dir, vsub(vscale(vscale(h, 2.0f), std_max(0.0f, vdot(V, h))), V));
             return 1;
         }
-        v3 dir = vsub(vscale(h, (eta * vDotH - sqrtf(k))), vscale(V, eta));
+        v3 dir = vsub(vscale(h, (eta * cos_vh - sqrtf(k))), vscale(V, eta));
         vst(o->dir, dir);
         const float absCos = fabsf(vdot(N, dir));
         if (absCos < 1e-5f) return 0;
-        const float F = fresnelRatio + (1.0f - fresnelRatio) * powf(1.0f - vDotH, 5.0f);
+        const float F = schlick + (1.0f - schlick) * powf(1.0f - cos_vh, 5.0f);
         const float tf = 1.0f - F;
         if (orc_rng_float(rng) > tf) {
             vst(o->dir, vsub(vscale(vscale(h, 2.0f), std_max(0.0f, vdot(V, h))), V));
@@ -811,13 +811,13 @@ float orc_mtl_pdf(const rt_material *m, const orc_surface *s, const float dir3[3
         prob += pd * pdfD;
     }
     const v3 h = vnormalize(vadd(V, dir));
-    const float nDotH = vdot(N, h);
-    const float vDotH = vdot(V, h);
-    if (isRefl && nDotH > 0.0f && vDotH > 0.0f && ps > 0.0f) {
+    const float cos_nh = vdot(N, h);
+    const float cos_vh = vdot(V, h);
+    if (isRefl && cos_nh > 0.0f && cos_vh > 0.0f && ps > 0.0f) {
         const float alpha = m->glossiness;
-        const float specNorm = (alpha + 2.0f) / (8.0f * PI_F);
-        const float pdfH = specNorm * powf(nDotH, alpha);
-        const float pdfS = pdfH / (4.0f * vDotH);
+        const float lobe_scale = (alpha + 2.0f) / (8.0f * PI_F);
+        const float half_pdf = lobe_scale * powf(cos_nh, alpha);
+        const float pdfS = half_pdf / (4.0f * cos_vh);
         prob += ps * pdfS;
     }
     return prob;
@@ -1380,21 +1380,21 @@ static v3 whitted_shade(const wctx *C, const wshade *s, const rt_material *m)
     const rt_scene_desc *sc = C->sc;
     v3 final = vld(m->emission);
     const v3 normal = vnormalize(s->n);
-    const v3 diffuseColor = textured_color(sc, m->diffuse, m->diffuse_texture, s->uvw); /* diffuse.Eval(shadeInfo.UVW()) */
+    const v3 kd_here = textured_color(sc, m->diffuse, m->diffuse_texture, s->uvw); /* diffuse.Eval(shadeInfo.UVW()) */
     const v3 specular = vld(m->specular);
     const float gloss = m->glossiness;
     const int pm = C->prm->photon_flags;
     for (uint32_t i = 0; i < sc->n_lights && !(pm & RT_PM_DIRECT); ++i) {
         const rt_light *l = &sc->lights[i];
         v3 lightDir;
-        const v3 lightIntensity = w_illuminate(C, l, s->p, &lightDir);
-        if (l->type == RT_LIGHT_AMBIENT) { final = vadd(final, vmul(diffuseColor, lightIntensity)); continue; }
-        const float geometryTerm = std_max(0.0f, vdot(normal, lightDir));
-        final = vadd(final, vscale(vmul(vscale(diffuseColor, (float)(1.0f / M_PI)), lightIntensity), geometryTerm));
-        const v3 halfway = vnormalize(vadd(s->v, lightDir));
-        const float blinnTerm = std_max(0.0f, vdot(normal, halfway));
+        const v3 light_in = w_illuminate(C, l, s->p, &lightDir);
+        if (l->type == RT_LIGHT_AMBIENT) { final = vadd(final, vmul(kd_here, light_in)); continue; }
+        const float cos_light = std_max(0.0f, vdot(normal, lightDir));
+        final = vadd(final, vscale(vmul(vscale(kd_here, (float)(1.0f / M_PI)), light_in), cos_light));
+        const v3 half_dir = vnormalize(vadd(s->v, lightDir));
+        const float cos_half = std_max(0.0f, vdot(normal, half_dir));
         const float k = (float)((gloss + 2.0f) / (8.0f * M_PI));
-        final = vadd(final, vscale(vmul(vscale(vscale(specular, k), powf(blinnTerm, gloss)), lightIntensity), geometryTerm));
+        final = vadd(final, vscale(vmul(vscale(vscale(specular, k), powf(cos_half, gloss)), light_in), cos_light));
     }
     /* irradiance from the photon maps (p12 materials.cpp:49-70); the reference also runs the estimate for a
      * specular surface that is no photon surface and then drops the result */
@@ -1403,20 +1403,20 @@ static v3 whitted_shade(const wctx *C, const wshade *s, const rt_material *m)
         float e[3];
         const uint64_t v = orc_photon_irradiance(g_map[0], g_map_n[0], pos3, nrm3, C->prm->gather_radius, e);
         if (C->st) { C->st->gathers++; C->st->photon_visits += v; }
-        final = vadd(final, vmul(vscale(diffuseColor, (float)(1.0f / M_PI)), vld(e)));
+        final = vadd(final, vmul(vscale(kd_here, (float)(1.0f / M_PI)), vld(e)));
     }
     if ((pm & RT_PM_CAUSTICS) && is_photon_surface(m)) {
         float e[3];
         const uint64_t v = orc_photon_irradiance(g_map[1], g_map_n[1], pos3, nrm3, C->prm->gather_radius, e);
         if (C->st) { C->st->gathers++; C->st->photon_visits += v; }
-        final = vadd(final, vmul(vscale(diffuseColor, (float)(1.0f / M_PI)), vld(e)));
+        final = vadd(final, vmul(vscale(kd_here, (float)(1.0f / M_PI)), vld(e)));
     }
     if (!(s->bounce < C->prm->max_bounces)) return final; /* CanBounce (p12 renderer.h:180) */
 
     const int ps = C->p_sample;
     const int P16 = C->prm->halton_period;
     /* Monte-Carlo indirect light, first two bounces (p12 materials.cpp:74-103) */
-    if (!(pm & RT_PM_INDIRECT) && (diffuseColor.x + diffuseColor.y + diffuseColor.z) > 0.0f && s->bounce < 2) {
+    if (!(pm & RT_PM_INDIRECT) && (kd_here.x + kd_here.y + kd_here.z) > 0.0f && s->bounce < 2) {
         const float phiOffset = orc_rng_float(C->rng);
         const float thetaOffset = orc_rng_float(C->rng);
         const float phi = (float)(2.0f * M_PI * fmodf(C->halton[0][ps % P16] + phiOffset, 1.0f));
@@ -1429,7 +1429,7 @@ static v3 whitted_shade(const wctx *C, const wshade *s, const rt_material *m)
         ray_t r; r.p = vadd(s->p, vscale(dir, 0.0002f)); r.d = dir;
         float dist;
         v3 colorSum = V3(0, 0, 0);
-        colorSum = vadd(colorSum, vmul(w_secondary(C, s, r, &dist), diffuseColor));
+        colorSum = vadd(colorSum, vmul(w_secondary(C, s, r, &dist), kd_here));
         final = vadd(final, vdivs(colorSum, (float)1));
     }
     /* glossy reflection (p12 materials.cpp:106-133) */
@@ -1475,8 +1475,8 @@ static v3 whitted_shade(const wctx *C, const wshade *s, const rt_material *m)
             ray_t r; r.p = vadd(s->p, vscale(reflectionDir, 0.0002f)); r.d = reflectionDir;
             return vadd(final, vmul(w_secondary(C, s, r, &dist), refraction));
         }
-        const float fresnelRatio = (float)pow((double)((1 - m->ior) / (1 + m->ior)), 2.0);
-        const float F = (float)(fresnelRatio + (1 - fresnelRatio) * pow((double)(1 - viewDotH), 5.0));
+        const float schlick = (float)pow((double)((1 - m->ior) / (1 + m->ior)), 2.0);
+        const float F = (float)(schlick + (1 - schlick) * pow((double)(1 - viewDotH), 5.0));
         v3 colorFromReflection = V3(0, 0, 0);
         const v3 reflectionDir = vsub(vscale(vscale(h, 2), vdot(s->v, h)), s->v);
         if (vdot(reflectionDir, N) > 0.0f) {

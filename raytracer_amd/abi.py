@@ -122,6 +122,13 @@ class ProgressInfo(C.Structure):
 HIT_DTYPE = np.dtype([("z", "<f4"), ("p", "<f4", 3), ("n", "<f4", 3), ("uvw", "<f4", 3),
                       ("node", "<i4"), ("front", "<i4")])
 assert HIT_DTYPE.itemsize == C.sizeof(Hit)
+# rt_debug_samplers: queries and answers (rt_sampler_query / rt_sampler_answer)
+RT_SAMPLER_LIGHT, RT_SAMPLER_MATERIAL, RT_SAMPLER_PHOTON_MATERIAL, RT_SAMPLER_PHOTON_EMIT = 0, 1, 2, 3
+SAMPLER_QUERY_DTYPE = np.dtype([("p", "<f4", 3), ("n", "<f4", 3), ("v", "<f4", 3), ("front", "<i4"), ("dir", "<f4", 3),
+                                ("material", "<i4"), ("seq", "<u8"), ("seed", "<u8")])
+SAMPLER_ANSWER_DTYPE = np.dtype([("dir", "<f4", 3), ("mult", "<f4", 3), ("prob", "<f4"), ("dist", "<f4"), ("ok", "<i4"),
+                                 ("lobe", "<i4"), ("pdf", "<f4"), ("next_u32", "<u4"), ("origin", "<f4", 3), ("pad", "<f4")])
+assert SAMPLER_QUERY_DTYPE.itemsize == 72 and SAMPLER_ANSWER_DTYPE.itemsize == 64
 HIT_BRIEF_DTYPE = np.dtype([("t", "<f4"), ("node", "<i4"), ("face", "<u4"), ("front", "<i4"), ("u", "<f4"), ("v", "<f4")])
 assert HIT_BRIEF_DTYPE.itemsize == C.sizeof(HitBrief)
 

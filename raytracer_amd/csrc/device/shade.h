@@ -134,21 +134,21 @@ RT_DEV bool mtl_generate(const rt_material &m, const Surface &s, Rng &rng, Sampl
         const V3 h = (u * x + v * y) + Ns * cosT;
         const float vh = dot(V, h);
         o.dir = normalize((h * 2.0f) * std_max(0.0f, vh) - V);
-        const float nDotH = dot(Ns, h);
-        if (nDotH < 0.0f) return false;
-        const float pdfH = ((alpha + 1.0f) / (8.0f * kPi)) * powf(cosT, alpha);
-        o.prob = (pdfH / (4.0f * vh)) * ps;
-        const float specNorm = (alpha + 2.0f) / (8.0f * kPi);
-        o.mult = ((ks * specNorm) * powf(nDotH, alpha)) / (4.0f * vh);
+        const float cos_nh = dot(Ns, h);
+        if (cos_nh < 0.0f) return false;
+        const float half_pdf = ((alpha + 1.0f) / (8.0f * kPi)) * powf(cosT, alpha);
+        o.prob = (half_pdf / (4.0f * vh)) * ps;
+        const float lobe_scale = (alpha + 2.0f) / (8.0f * kPi);
+        o.mult = ((ks * lobe_scale) * powf(cos_nh, alpha)) / (4.0f * vh);
         return true;
     }
     if (rnd < pd + ps + pt) {
         o.lobe = LOBE_TRANSMISSION;
-        const float fresnelRatio = powf((1.0f - m.ior) / (1.0f + m.ior), 2.0f);
+        const float schlick = powf((1.0f - m.ior) / (1.0f + m.ior), 2.0f);
         V3 N = Ns;
-        float etaI = 1.0f, etaT = m.ior;
-        if (!s.front) { N = -N; const float t = etaI; etaI = etaT; etaT = t; }
-        const float eta = etaI / etaT;
+        float n_from = 1.0f, n_into = m.ior;
+        if (!s.front) { N = -N; const float t = n_from; n_from = n_into; n_into = t; }
+        const float eta = n_from / n_into;
         const float alpha = m.glossiness;
         const float phi = 2.0f * kPi * rng_float(rng);
         const float cosT = powf(1.0f - rng_float(rng), 1.0f / (alpha + 1.0f));
@@ -160,16 +160,16 @@ RT_DEV bool mtl_generate(const rt_material &m, const Surface &s, Rng &rng, Sampl
         V3 u, v;
         orthonormals(N, u, v);
         const V3 h = (u * x + v * y) + N * cosT;
-        const float vDotH = dot(V, h);
-        const float k = 1.0f - eta * eta * (1.0f - vDotH * vDotH);
+        const float cos_vh = dot(V, h);
+        const float k = 1.0f - eta * eta * (1.0f - cos_vh * cos_vh);
         o.mult = kt;
         o.prob = pt;
-        const V3 refl = (h * 2.0f) * std_max(0.0f, vDotH) - V;
+        const V3 refl = (h * 2.0f) * std_max(0.0f, cos_vh) - V;
         if (k < 0.0f) { o.dir = refl; return true; }
-        const V3 dir = h * (eta * vDotH - fsqrt(k)) - V * eta;
+        const V3 dir = h * (eta * cos_vh - fsqrt(k)) - V * eta;
         o.dir = dir;
         if (fabsf(dot(N, dir)) < 1e-5f) return false;
-        const float F = fresnelRatio + (1.0f - fresnelRatio) * powf(1.0f - vDotH, 5.0f);
+        const float F = schlick + (1.0f - schlick) * powf(1.0f - cos_vh, 5.0f);
         const float tf = 1.0f - F;
         if (rng_float(rng) > tf) o.dir = refl;
         return true;
@@ -187,13 +187,13 @@ RT_DEV float mtl_pdf(const rt_material &m, const Surface &s, V3 dir)
     float prob = 0.0f;
     if (pd > 0.0f && isRefl) prob += pd * (nDotDir / kPi);
     const V3 h = normalize(s.v + dir);
-    const float nDotH = dot(s.n, h);
-    const float vDotH = dot(s.v, h);
-    if (isRefl && nDotH > 0.0f && vDotH > 0.0f && ps > 0.0f) {
+    const float cos_nh = dot(s.n, h);
+    const float cos_vh = dot(s.v, h);
+    if (isRefl && cos_nh > 0.0f && cos_vh > 0.0f && ps > 0.0f) {
         const float alpha = m.glossiness;
-        const float specNorm = (alpha + 2.0f) / (8.0f * kPi);
-        const float pdfH = specNorm * powf(nDotH, alpha);
-        prob += ps * (pdfH / (4.0f * vDotH));
+        const float lobe_scale = (alpha + 2.0f) / (8.0f * kPi);
+        const float half_pdf = lobe_scale * powf(cos_nh, alpha);
+        prob += ps * (half_pdf / (4.0f * cos_vh));
     }
     return prob;
 }

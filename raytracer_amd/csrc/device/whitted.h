@@ -92,10 +92,10 @@ RT_DEV float whitted_cos2(float ratio, float viewDotH)
 RT_DEV float whitted_fresnel(float ior, float viewDotH)
 {
     const double b = (double)((1 - ior) / (1 + ior));
-    const float fresnelRatio = (float)(b * b);
+    const float schlick = (float)(b * b);
     const double a = (double)(1 - viewDotH);
     const double a2 = a * a;
-    return (float)(fresnelRatio + (1 - fresnelRatio) * (a2 * a2 * a));
+    return (float)(schlick + (1 - schlick) * (a2 * a2 * a));
 }
 
 template <bool COUNT, int LEVELS>

@@ -1,10 +1,12 @@
 // C ABI of the GPU backend: context, scene upload, frame rendering, batch queries.
 // Host-side control only; the arithmetic lives in device/*.h.
 #include "device/wavefront.h"
-#include <hipcub/hipcub.hpp>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 #include "device/whitted.h"
 #include "device/kdbuild.h"
 #include "device/lbvh.h"
+#include "device/debug.h"
 #include "rt_mi355x.h"
 
 #include <algorithm>
@@ -623,11 +625,11 @@ static int build_bvh_gpu(rt_ctx *ctx, const rt_mesh &m, uint32_t node_base, uint
     const auto scale = [&](int a) { return hi[a] > lo[a] ? 2097151.0f / (hi[a] - lo[a]) : 0.0f; };
     hipLaunchKernelGGL(k_lbvh_keys, grid, block, 0, s, A, lo[0], lo[1], lo[2], scale(0), scale(1), scale(2));
     size_t tmp_bytes = 0;
-    HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys[0].as<unsigned long long>(), keys[1].as<unsigned long long>(),
-                                                    order[0].as<uint32_t>(), order[1].as<uint32_t>(), (int)n, 0, 63, s));
+    HIP_TRY(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys[0].as<unsigned long long>(), keys[1].as<unsigned long long>(),
+                                           order[0].as<uint32_t>(), order[1].as<uint32_t>(), (size_t)n, 0u, 63u, s));
     HIP_TRY(ctx, tmp.reserve(std::max<size_t>(1, tmp_bytes)));
-    HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, keys[0].as<unsigned long long>(), keys[1].as<unsigned long long>(),
-                                                    order[0].as<uint32_t>(), order[1].as<uint32_t>(), (int)n, 0, 63, s));
+    HIP_TRY(ctx, rocprim::radix_sort_pairs(tmp.p, tmp_bytes, keys[0].as<unsigned long long>(), keys[1].as<unsigned long long>(),
+                                           order[0].as<uint32_t>(), order[1].as<uint32_t>(), (size_t)n, 0u, 63u, s));
     A.keys = keys[1].as<unsigned long long>(); A.order = order[1].as<uint32_t>();
     LbvhOut O{};
     O.node_base = node_base; O.rec_base = rec_base; O.tri_base = tri_base;
@@ -640,9 +642,9 @@ static int build_bvh_gpu(rt_ctx *ctx, const rt_mesh &m, uint32_t node_base, uint
         hipLaunchKernelGGL(k_lbvh_mark_inner, grid, block, 0, s, A);
         const auto scan = [&](DeviceBuf &flags, DeviceBuf &ranks, uint32_t &total) -> int {
             size_t bytes = 0;
-            HIP_TRY(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, flags.as<uint32_t>(), ranks.as<uint32_t>(), (int)(n - 1), s));
+            HIP_TRY(ctx, rocprim::exclusive_scan(nullptr, bytes, flags.as<uint32_t>(), ranks.as<uint32_t>(), 0u, (size_t)(n - 1), rocprim::plus<uint32_t>(), s));
             HIP_TRY(ctx, tmp.reserve(std::max<size_t>(1, bytes)));
-            HIP_TRY(ctx, hipcub::DeviceScan::ExclusiveSum(tmp.p, bytes, flags.as<uint32_t>(), ranks.as<uint32_t>(), (int)(n - 1), s));
+            HIP_TRY(ctx, rocprim::exclusive_scan(tmp.p, bytes, flags.as<uint32_t>(), ranks.as<uint32_t>(), 0u, (size_t)(n - 1), rocprim::plus<uint32_t>(), s));
             uint32_t last[2] = {0, 0};
             HIP_TRY(ctx, hipMemcpyAsync(&last[0], flags.as<uint32_t>() + (n - 2), 4, hipMemcpyDeviceToHost, s));
             HIP_TRY(ctx, hipMemcpyAsync(&last[1], ranks.as<uint32_t>() + (n - 2), 4, hipMemcpyDeviceToHost, s));
@@ -1242,11 +1244,11 @@ int rt_render(rt_ctx *ctx, const rt_render_params *prm, rt_frame_out *out)
         void *args[] = {&a_scene, &F, &a_hal, &a_act, &a_n, &a_keys};
         HIP_TRY(ctx, hipLaunchKernel(fn, grid, dim3(kBlock), args, stack_lds_bytes(ctx->scene), s));
         size_t tmp_bytes = 0;
-        HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tmp_bytes, ctx->d_keys[0].as<uint32_t>(), ctx->d_keys[1].as<uint32_t>(),
-                                                                  first_list, ctx->d_active_sorted.as<int32_t>(), (int)n0, 0, 24, s));
+        HIP_TRY(ctx, rocprim::radix_sort_pairs_desc(nullptr, tmp_bytes, ctx->d_keys[0].as<uint32_t>(), ctx->d_keys[1].as<uint32_t>(),
+                                                    first_list, ctx->d_active_sorted.as<int32_t>(), (size_t)n0, 0u, 24u, s));
         HIP_TRY(ctx, ctx->d_sort_tmp.reserve(std::max<size_t>(1, tmp_bytes)));
-        HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairsDescending(ctx->d_sort_tmp.p, tmp_bytes, ctx->d_keys[0].as<uint32_t>(), ctx->d_keys[1].as<uint32_t>(),
-                                                                  first_list, ctx->d_active_sorted.as<int32_t>(), (int)n0, 0, 24, s));
+        HIP_TRY(ctx, rocprim::radix_sort_pairs_desc(ctx->d_sort_tmp.p, tmp_bytes, ctx->d_keys[0].as<uint32_t>(), ctx->d_keys[1].as<uint32_t>(),
+                                                    first_list, ctx->d_active_sorted.as<int32_t>(), (size_t)n0, 0u, 24u, s));
         first_list = ctx->d_active_sorted.as<int32_t>();
     }
 
@@ -1808,47 +1810,58 @@ int rt_photons_build(rt_ctx *ctx, int which, const rt_photon *photons, uint32_t 
     A.in = d_in; A.out = ctx->pmap(which); A.n = n;
     A.scale = 1.0f / (float)(int)n; // ScalePhotonPowers(1 / NumPhotons()) (src/photonmap.h:82)
     const uint32_t init_words[7] = {0x80000000u, 0x80000000u, 0x80000000u, 0x80000000u, 0x80000000u, 0x80000000u, 0u};
-    HIP_TRY(ctx, hipMemcpyAsync(d_box_bits, init_words, sizeof init_words, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipEventRecord(ctx->evk0, st));
-    {
-        const uint32_t blocks = (uint32_t)std::min<size_t>(((size_t)n + 255) / 256, (size_t)ctx->n_cu * 8);
-        hipLaunchKernelGGL(rtd::k_kd_init, dim3(blocks), dim3(256), 0, st, A, d_box_bits, d_bad);
-        hipLaunchKernelGGL(rtd::k_kd_root_box, dim3(1), dim3(64), 0, st, A, (const uint32_t *)d_box_bits);
-    }
-    uint32_t bad = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipStreamSynchronize(st));
-    if (bad) return ctx->fail(RT_ERR_INVALID, "a photon has a non-finite position"); // the quick-select would not terminate
     // One launch per level.  While a level has fewer segments than the chip has compute units and they are long, a
     // crowd of workgroups shares each segment; then a workgroup per segment, sized to the level's largest segment (its
     // leftmost); segments of kKdTiny photons or fewer are finished by one lane each.
+    // A crowd's workgroups meet at barriers of their own and must all be resident; if something else holds compute
+    // units (another process, another stream) they can wait in vain, notice, and leave a half-partitioned segment.
+    // The build then starts over from the caller's photons with a workgroup per segment on every level: slower
+    // (about ten times for ten million photons), the same tree.
+    const bool test_abort = getenv("RT_KD_TEST_ABORT") != nullptr; // (test hook: treat the first attempt as given up)
     uint32_t grid_max = 1;
     while (grid_max * 2 <= (uint32_t)std::min(ctx->n_cu, 256)) grid_max *= 2; // every workgroup of a crowd launch must be resident
-    for (int level = 0; level < rtd::kKdMaxLevels && n >= 2; ++level) {
-        const uint32_t first = 1u << level;
-        if (first > n) break;
-        const uint32_t nodes = std::min<uint32_t>(first, n - first + 1);
-        int s0, e0;
-        if (!rtd::kd_segment(n, first, s0, e0)) break; // nothing left with two or more photons
-        const int largest = e0 - s0 + 1;
-        if (largest <= rtd::kKdTiny) {
-            hipLaunchKernelGGL(rtd::k_kd_tiny, dim3((nodes + 63) / 64), dim3(64), 0, st, A, first, nodes);
-            break;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const bool crowds = attempt == 0;
+        HIP_TRY(ctx, hipMemcpyAsync(d_box_bits, init_words, sizeof init_words, hipMemcpyHostToDevice, st));
+        {
+            const uint32_t blocks = (uint32_t)std::min<size_t>(((size_t)n + 255) / 256, (size_t)ctx->n_cu * 8);
+            hipLaunchKernelGGL(rtd::k_kd_init, dim3(blocks), dim3(256), 0, st, A, d_box_bits, d_bad);
+            hipLaunchKernelGGL(rtd::k_kd_root_box, dim3(1), dim3(64), 0, st, A, (const uint32_t *)d_box_bits);
         }
-        const uint32_t crowd = grid_max >> std::min(level, 31);
-        if (crowd >= 2 && largest > rtd::kKdAloneBelow) {
-            HIP_TRY(ctx, hipMemsetAsync(d_crowd, 0, crowd_bytes, st));
-            hipLaunchKernelGGL((rtd::k_kd_level_crowd<1024, 8>), dim3(first * crowd), dim3(1024), 0, st, A, first, crowd, d_crowd, d_bad);
+        uint32_t bad = 0;
+        HIP_TRY(ctx, hipMemcpyAsync(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        if (bad) return ctx->fail(RT_ERR_INVALID, "a photon has a non-finite position"); // the quick-select would not terminate
+        for (int level = 0; level < rtd::kKdMaxLevels && n >= 2; ++level) {
+            const uint32_t first = 1u << level;
+            if (first > n) break;
+            const uint32_t nodes = std::min<uint32_t>(first, n - first + 1);
+            int s0, e0;
+            if (!rtd::kd_segment(n, first, s0, e0)) break; // nothing left with two or more photons
+            const int largest = e0 - s0 + 1;
+            if (largest <= rtd::kKdTiny) {
+                hipLaunchKernelGGL(rtd::k_kd_tiny, dim3((nodes + 63) / 64), dim3(64), 0, st, A, first, nodes);
+                break;
+            }
+            const uint32_t crowd = grid_max >> std::min(level, 31);
+            if (crowds && crowd >= 2 && largest > rtd::kKdAloneBelow) {
+                HIP_TRY(ctx, hipMemsetAsync(d_crowd, 0, crowd_bytes, st));
+                hipLaunchKernelGGL((rtd::k_kd_level_crowd<1024, 8>), dim3(first * crowd), dim3(1024), 0, st, A, first, crowd, d_crowd, d_bad);
+            }
+            else if (largest > 16384) hipLaunchKernelGGL((rtd::k_kd_level<1024, 8>), dim3(nodes), dim3(1024), 0, st, A, first, nodes);
+            else if (largest > 2048) hipLaunchKernelGGL((rtd::k_kd_level<256, 8>), dim3(nodes), dim3(256), 0, st, A, first, nodes);
+            else hipLaunchKernelGGL((rtd::k_kd_level<64, 4>), dim3(nodes), dim3(64), 0, st, A, first, nodes);
         }
-        else if (largest > 16384) hipLaunchKernelGGL((rtd::k_kd_level<1024, 8>), dim3(nodes), dim3(1024), 0, st, A, first, nodes);
-        else if (largest > 2048) hipLaunchKernelGGL((rtd::k_kd_level<256, 8>), dim3(nodes), dim3(256), 0, st, A, first, nodes);
-        else hipLaunchKernelGGL((rtd::k_kd_level<64, 4>), dim3(nodes), dim3(64), 0, st, A, first, nodes);
+        HIP_TRY(ctx, hipMemcpyAsync(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        if (crowds && test_abort) bad = 1;
+        if (!bad) break;
+        if (!crowds) return ctx->fail(RT_ERR_HIP, "kd-tree build failed without shared segments");
     }
-    HIP_TRY(ctx, hipMemcpyAsync(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->evk1, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
-    if (bad) return ctx->fail(RT_ERR_HIP, "kd-tree build: workgroups sharing a segment waited for each other in vain (were they not all resident?)");
     float build_ms = 0;
     HIP_TRY(ctx, hipEventElapsedTime(&build_ms, ctx->evk0, ctx->evk1));
     ctx->counters = rt_counters{};
@@ -1900,6 +1913,52 @@ int rt_photons_fill(rt_ctx *ctx, const rt_photon_params *pp)
     ctx->counters = rt_counters{};
     ctx->counters.closest_rays = rays; ctx->counters.camera_paths = paths_total;
     ctx->counters.kernel_ms = emit_ms; ctx->counters.trace_kernel_ms = emit_ms;
+    return RT_OK;
+}
+
+int rt_debug_samplers(rt_ctx *ctx, int which, const rt_sampler_query *queries, int n, rt_sampler_answer *out)
+{
+    if (!ctx) return RT_ERR_INVALID;
+    if (!ctx->have_scene) return ctx->fail(RT_ERR_STATE, "no scene uploaded");
+    if (which < RT_SAMPLER_LIGHT || which > RT_SAMPLER_PHOTON_EMIT) return ctx->fail(RT_ERR_INVALID, "unknown sampler %d", which);
+    if (n < 0 || (n > 0 && (!queries || !out))) return ctx->fail(RT_ERR_INVALID, "bad query arrays");
+    if (n == 0) return RT_OK;
+    uint32_t n_materials = (uint32_t)(ctx->d_materials.bytes / sizeof(rt_material));
+    for (int i = 0; i < n; ++i)
+        if (queries[i].material < 0 || (uint32_t)queries[i].material >= n_materials) return ctx->fail(RT_ERR_INVALID, "query %d: material index out of range", i);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    HIP_TRY(ctx, ctx->d_q_in.reserve((size_t)n * sizeof(rt_sampler_query)));
+    HIP_TRY(ctx, ctx->d_q_out.reserve((size_t)n * sizeof(rt_sampler_answer)));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_q_in.p, queries, (size_t)n * sizeof(rt_sampler_query), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_debug_samplers, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, ctx->scene, which,
+                       ctx->d_q_in.as<rt_sampler_query>(), n, ctx->d_q_out.as<rt_sampler_answer>());
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(out, ctx->d_q_out.p, (size_t)n * sizeof(rt_sampler_answer), hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    return RT_OK;
+}
+
+int rt_debug_rng(rt_ctx *ctx, const uint64_t *seq, const uint64_t *seed, int n_streams, int n_draws, uint32_t *words, float *floats)
+{
+    if (!ctx) return RT_ERR_INVALID;
+    if (n_streams < 0 || n_draws < 0 || (n_streams > 0 && n_draws > 0 && (!seq || !seed || !words || !floats))) return ctx->fail(RT_ERR_INVALID, "bad arrays");
+    if (n_streams == 0 || n_draws == 0) return RT_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const size_t total = (size_t)n_streams * n_draws;
+    HIP_TRY(ctx, ctx->d_q_in.reserve((size_t)n_streams * 16));
+    HIP_TRY(ctx, ctx->d_q_out.reserve(total * 8));
+    uint64_t *d_seq = ctx->d_q_in.as<uint64_t>(), *d_seed = d_seq + n_streams;
+    uint32_t *d_words = ctx->d_q_out.as<uint32_t>();
+    float *d_floats = (float *)(d_words + total);
+    HIP_TRY(ctx, hipMemcpyAsync(d_seq, seq, (size_t)n_streams * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(d_seed, seed, (size_t)n_streams * 8, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_debug_rng, dim3((n_streams + kBlock - 1) / kBlock), dim3(kBlock), 0, s, d_seq, d_seed, n_streams, n_draws, d_words, d_floats);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(words, d_words, total * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipMemcpyAsync(floats, d_floats, total * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
     return RT_OK;
 }
 

@@ -96,6 +96,8 @@ def load():
     L.rt_photons_fill.argtypes = [vp, C.POINTER(abi.PhotonParams)]
     L.rt_photons_download.argtypes = [vp, C.c_int, vp, C.POINTER(C.c_uint32)]
     L.rt_photons_irradiance.argtypes = [vp, C.c_int, abi.f32p, abi.f32p, C.c_int, C.c_float, abi.f32p]
+    L.rt_debug_samplers.argtypes = [vp, C.c_int, vp, C.c_int, vp]
+    L.rt_debug_rng.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp]
     _lib = L
     return L
 
@@ -309,6 +311,22 @@ class Context:
         self._check(self._L.rt_trace_paths(self._h, rays.ctypes.data_as(abi.f32p), len(rays), seed, C.byref(params),
                                            out.ctypes.data_as(abi.f32p)))
         return out
+
+    # ---- known-answer queries (tests) ----
+    def debug_samplers(self, which, queries):
+        """rt_debug_samplers: queries = array of abi.SAMPLER_QUERY_DTYPE -> array of abi.SAMPLER_ANSWER_DTYPE."""
+        q = np.ascontiguousarray(queries, abi.SAMPLER_QUERY_DTYPE)
+        out = np.zeros(len(q), abi.SAMPLER_ANSWER_DTYPE)
+        self._check(self._L.rt_debug_samplers(self._h, which, q.ctypes.data, len(q), out.ctypes.data))
+        return out
+
+    def debug_rng(self, seq, seed, n_draws):
+        """rt_debug_rng: (words, floats), each [streams, n_draws]."""
+        seq, seed = np.ascontiguousarray(seq, np.uint64), np.ascontiguousarray(seed, np.uint64)
+        words = np.zeros((len(seq), n_draws), np.uint32)
+        floats = np.zeros((len(seq), n_draws), np.float32)
+        self._check(self._L.rt_debug_rng(self._h, seq.ctypes.data, seed.ctypes.data, len(seq), n_draws, words.ctypes.data, floats.ctypes.data))
+        return words, floats
 
     # ---- photon maps ----
     def photons_emit(self, pp, which, path_begin, path_count, capacity, device_ptr=0):

@@ -680,3 +680,96 @@ def test_object_hierarchy_changes_nothing(monkeypatch, tmp_path):
         assert np.array_equal(bits(a.linear), bits(b.linear)), f"scene {k}: radiance"
         assert np.array_equal(a.rgb, b.rgb) and np.array_equal(a.sample_count, b.sample_count)
         assert (a.object_id >= 0).mean() > 0.3
+
+
+# ---------------------------------------------------------------- samplers and random streams, value for value
+def _unit(v):
+    """cyVector's Normalize on float32 rows: component / sqrt((x*x + y*y) + z*z)."""
+    f = np.float32
+    v = np.asarray(v, f)
+    l = np.sqrt((v[:, 0] * v[:, 0] + v[:, 1] * v[:, 1]).astype(f) + (v[:, 2] * v[:, 2]).astype(f), dtype=f)
+    return (v / l[:, None]).astype(f)
+
+
+def test_random_streams_on_the_device(ctx):
+    """PCG32 as the kernels compute it (64-bit multiply-add in 32-bit pieces, XSH-RR, float conversion with its clamp)
+    against the reference's RNG: the streams of the fixture, word for word and float for float (src/rng.h:29-65)."""
+    g = O.load_golden("rng")
+    seqs = np.array([0, 1, 921599, 0xFFFFFFFFFF], np.uint64)
+    seeds = np.array([0, 42, 0x9E3779B97F4A7C15, 7], np.uint64)
+    words, floats = ctx.debug_rng(seqs, seeds, 64)
+    assert np.array_equal(words, g["rng_u32"])
+    assert np.array_equal(bits(floats), bits(g["rng_f32"]))
+
+
+def test_samplers_on_the_device_vs_reference(ctx):
+    """The light and material samplers the shading kernels call, evaluated on the device on the fixture's inputs
+    (1024 surface points x the scene's six materials), against the reference's own GenerateSample / GetSampleInfo:
+    the lobe chosen, the number of random numbers drawn and the probabilities of GetSampleInfo bit for bit wherever
+    only IEEE arithmetic is involved; directions and weights that pass through the device's sinf / cosf / powf to a
+    few ulp (those functions differ from glibc's in the last place)."""
+    g = O.load_golden("kat_samplers_a")
+    s = O.scene_from_golden(g)
+    ctx.upload(s.desc)
+    inp, n = g["smp_in"], len(g["smp_in"])
+    q = np.zeros(n, abi.SAMPLER_QUERY_DTYPE)
+    q["p"], q["n"], q["v"], q["dir"] = inp[:, 0:3], _unit(inp[:, 3:6]), -_unit(inp[:, 6:9]), inp[:, 9:12]
+    q["front"] = g["smp_front"]
+    q["seq"], q["seed"] = np.arange(1, n + 1), 5
+    a = ctx.debug_samplers(abi.RT_SAMPLER_LIGHT, q)
+    ref = g["smp_light_gen"]  # dir, mult, prob, dist, ok
+    np.testing.assert_allclose(a["dir"], ref[:, 0:3], rtol=0, atol=3e-6)
+    assert np.array_equal(bits(a["mult"]), bits(ref[:, 3:6]))
+    np.testing.assert_allclose(a["prob"], ref[:, 6], rtol=2e-6)
+    np.testing.assert_allclose(a["dist"], ref[:, 7], rtol=2e-6)
+    exact = (bits(a["dir"]) == bits(ref[:, 0:3])).all(axis=1).mean()
+    assert exact > 0.5, f"only {exact:.3f} of the light samples are bit-identical"
+    np.testing.assert_allclose(a["pdf"], g["smp_light_pdf"], rtol=2e-6)
+    lobes = set()
+    for m in range(s.desc.n_materials):
+        q["material"], q["seed"] = m, 5 ^ (0x1000 + m)
+        a = ctx.debug_samplers(abi.RT_SAMPLER_MATERIAL, q)
+        fl, ref = g["smp_mtl_flags"][:, m], g["smp_mtl_gen"][:, m]
+        same_branch = (a["ok"] == fl[:, 0]) & (a["next_u32"] == fl[:, 2].astype(np.uint32)) & ((a["lobe"] == fl[:, 1]) | (fl[:, 0] == 0))
+        assert same_branch.mean() >= 0.995, f"material {m}: {np.sum(~same_branch)} samples take another branch"
+        ok = same_branch & (fl[:, 0] != 0)
+        lobes |= set(fl[ok, 1].tolist())
+        # (near the axis of a sharp lobe, sin(theta) = sqrt(1 - cos^2) amplifies the last bit of powf a thousandfold)
+        np.testing.assert_allclose(a["dir"][ok], ref[ok, 0:3], rtol=0, atol=2e-4)
+        assert (np.abs(a["dir"][ok] - ref[ok, 0:3]).max(axis=1) <= 3e-6).mean() >= 0.99
+        np.testing.assert_allclose(a["mult"][ok], ref[ok, 3:6], rtol=2e-4, atol=1e-7)
+        np.testing.assert_allclose(a["prob"][ok], ref[ok, 6], rtol=2e-4, atol=1e-7)
+        np.testing.assert_allclose(a["pdf"], g["smp_mtl_pdf"][:, m], rtol=2e-4, atol=1e-7)
+    assert lobes == {1, 2, 4}
+
+
+def test_photon_samplers_on_the_device_vs_reference(ctx):
+    """PointLight::RandomPhoton and the snapshot's scattering sampler on the device against the reference's (double
+    sin / cos / pow narrowed once, as the snapshot computes them): draws consumed and branches equal, values to a few ulp."""
+    g = O.load_golden("kat_photon_a")
+    s = O.scene_from_golden(g)
+    ctx.upload(s.desc)
+    seed = int(g["seed"])
+    n = len(g["ph_emit"])
+    q = np.zeros(n, abi.SAMPLER_QUERY_DTYPE)
+    q["seq"], q["seed"] = np.arange(n), seed ^ 0x50484F54
+    a = ctx.debug_samplers(abi.RT_SAMPLER_PHOTON_EMIT, q)
+    got = np.concatenate([a["origin"], a["dir"], a["mult"]], axis=1)
+    same = (bits(got) == bits(g["ph_emit"])).all(axis=1)
+    assert same.mean() >= 0.99, f"only {same.mean():.3f} of the emitted photons are bit-identical"
+    np.testing.assert_allclose(got, g["ph_emit"], rtol=1e-5, atol=1e-5)
+    inp, fl, gen = g["ph_smp_in"], g["ph_smp_flags"], g["ph_smp_gen"]
+    n = len(inp)
+    q = np.zeros(n, abi.SAMPLER_QUERY_DTYPE)
+    q["p"], q["n"], q["v"] = inp[:, 0:3], _unit(inp[:, 3:6]), -_unit(inp[:, 6:9])
+    q["front"] = g["ph_smp_front"]
+    q["seq"] = np.arange(1, n + 1)
+    for m in range(gen.shape[1]):
+        q["material"], q["seed"] = m, seed ^ (0x2000 + m)
+        a = ctx.debug_samplers(abi.RT_SAMPLER_PHOTON_MATERIAL, q)
+        same_branch = (a["ok"] == fl[:, m, 0]) & (a["next_u32"] == (fl[:, m, 2].astype(np.int64) & 0xFFFFFFFF).astype(np.uint32)) & ((a["lobe"] == fl[:, m, 1]) | (fl[:, m, 0] == 0))
+        assert same_branch.mean() >= 0.995, f"material {m}: {np.sum(~same_branch)} samples take another branch"
+        ok = same_branch & (fl[:, m, 0] != 0)
+        got = np.concatenate([a["dir"], a["mult"], a["prob"][:, None]], axis=1)
+        np.testing.assert_allclose(got[ok], gen[ok, m], rtol=2e-4, atol=2e-4)
+        assert (np.abs(got[ok] - gen[ok, m]).max(axis=1) <= 1e-5 * np.maximum(1.0, np.abs(gen[ok, m]).max(axis=1))).mean() >= 0.99

@@ -65,3 +65,21 @@ def test_non_finite_position_is_refused(ctx):
     raw["pos"][17, 1] = np.nan
     with pytest.raises(lib.RtError):
         ctx.photons_build(abi.RT_MAP_GLOBAL, raw)
+
+
+def test_build_starts_over_without_shared_segments(ctx, monkeypatch):
+    """Workgroups that share a segment wait for each other at barriers of their own; if they cannot all run at once
+    (something else holds compute units) they give up, leaving the segment half partitioned.  rt_photons_build then
+    starts over from the caller's photons with one workgroup per segment - here forced by the test hook, from the
+    arrays a first complete build left behind: the same tree, node for node."""
+    raw = photons(400_000, "walls", 11)
+    want = O.photon_build(raw)
+    ctx.photons_build(abi.RT_MAP_GLOBAL, raw)
+    fast_ms = ctx.counters().kernel_ms
+    assert ctx.photons_download(abi.RT_MAP_GLOBAL).tobytes() == want.tobytes()
+    monkeypatch.setenv("RT_KD_TEST_ABORT", "1")
+    ctx.photons_build(abi.RT_MAP_GLOBAL, raw)
+    slow_ms = ctx.counters().kernel_ms
+    monkeypatch.delenv("RT_KD_TEST_ABORT")
+    assert ctx.photons_download(abi.RT_MAP_GLOBAL).tobytes() == want.tobytes()
+    assert slow_ms > fast_ms  # both attempts are in the time
