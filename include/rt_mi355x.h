@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 5
+#define RT_ABI_VERSION 6
 
 typedef struct rt_ctx rt_ctx;
 

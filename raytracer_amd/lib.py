@@ -23,6 +23,7 @@ SYMBOLS = (
     "rt_scene_host_free", "rt_scene_host_set_mesh", "rt_scene_host_set_face_materials", "rt_scene_host_set_gpu_bvh", "rt_scene_host_warning", "rt_png_decode_rgb8",
     "rt_bvh_build", "rt_free",
     "rt_cancel", "rt_progress", "rt_frame_records", "rt_frame_pack", "rt_frame_unpack", "rt_photons_emit", "rt_photons_build", "rt_photons_fill", "rt_photons_download", "rt_photons_irradiance",
+    "rt_debug_samplers", "rt_debug_rng",
 )
 
 _lib = None
