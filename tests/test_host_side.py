@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(lib.SYMBOLS)
     for name in declared:
         assert hasattr(L, name), name
-    assert L.rt_abi_version() == 5
+    assert L.rt_abi_version() == 6
 
 
 def test_struct_sizes_match_header(tmp_path):
