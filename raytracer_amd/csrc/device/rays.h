@@ -194,6 +194,72 @@ template <bool COUNT, int LEVELS, class IO> struct RayWalker {
     // sphere would skip box and triangle tests the reference makes.)
     static constexpr bool kDeferMesh = !COUNT;
 
+    // Scenes of many objects (DScene::tlas: sixteen and more) are not walked object by object: the wave moves one cursor
+    // through the hierarchy over the objects' padded world boxes (depth-first records with skip links, so no stack),
+    // enters a record if any lane's ray reaches its box before that lane's closest hit so far, and only the lanes that
+    // reach a leaf's box take its object into account - the ray in the object's space rebuilt through the object's
+    // ancestors, the same products in the same order as the pass over the flat list forms them.  Objects come up in the
+    // hierarchy's order, not the list's: of two hits at exactly the same distance the object that is first in the list
+    // wins, as in the reference (strict <, objects in list order, src/main.cpp:38-48).  node_i is the lane's place among
+    // the records: a lane that comes back from a mesh (it had met a second one) goes on from there - on the way down
+    // to its place it follows the records that contain it and looks at nothing else.  (Not the counting variant: the
+    // reference tests every object, and the counters are the reference's.)
+    static constexpr bool kObjectHierarchy = !COUNT;
+    RT_DEV void scene_pass_hierarchy(const DScene &S, const IO &io, Tally<COUNT> &tl)
+    {
+        const bool mine = active && !in_bvh;
+        const V3 winv = cull_inverse(wray.d);
+        bool noted = false, stopped = false; // a mesh entry waits for the end of the pass; the lane has met a second mesh
+        int cursor = 0;
+        while (cursor < S.n_tlas) { // every lane of the wave stays in this loop to its end: the votes need them all
+            const int c = __builtin_amdgcn_readfirstlane(cursor);
+            const TlasNode &tn = S.tlas[c];
+            const int skip = tn.skip, obj = tn.object;
+            const bool here = mine && active && !in_bvh && !stopped;
+            const bool behind = c < node_i; // the lane has been past this record already
+            const bool reach = here && (behind ? skip > node_i : reaches_box(tn.box, wray.p, winv, any_hit ? t_max : best_t));
+            if (!__any(reach)) { cursor = skip; continue; }
+            cursor = c + 1;
+            if (obj < 0 || !reach || behind) continue;
+            const DNode &nd = S.nodes[obj];
+            Ray l = wray;
+            for (int k = 0; k <= nd.depth; ++k) l = to_node(S.nodes[nd.chain[k]], l);
+            const int prim = nd.prim;
+            if (prim == RT_PRIM_SPHERE || prim == RT_PRIM_PLANE) {
+                if (any_hit) {
+                    const bool occ = prim == RT_PRIM_SPHERE ? sphere_shadow(l, t_max) : plane_shadow(l, t_max);
+                    if (occ) { shadow_done(io, true); noted = false; }
+                } else {
+                    float t = 0; int front = 1;
+                    const bool ok = prim == RT_PRIM_SPHERE ? sphere_t(l, t, front) : plane_t(l, t, front);
+                    if (ok && (t < best_t || (t == best_t && obj < best_node))) { best_t = t; best_node = obj; best_front = front; best_face = 0; best_u = 0; best_v = 0; }
+                }
+            } else if (prim == RT_PRIM_MESH) {
+                const TNode &tm = S.tnodes[obj];
+                const V3 iv = mk(1.0f / l.d.x, 1.0f / l.d.y, 1.0f / l.d.z);
+                const bool ex = needs_exact_slabs(l.p, iv);
+                const float lim = any_hit ? t_max : FLT_MAX;
+                const f4 r0 = {tm.box[0], tm.box[1], tm.box[2], tm.box[3]}, r1 = {tm.box[4], tm.box[5], 0.0f, 0.0f};
+                float dist;
+                tl.boxes(1);
+                if (!bvh_box(ex, l.p, iv, lim, r0, r1, dist)) {}
+                else if (noted) { stopped = true; node_i = c; } // one walk at a time: come back to this record after it
+                else {
+                    lr = l; inv = iv; exact = ex; t_limit = lim; m_hit = false;
+                    cur = kWide ? tm.root4 : tm.root; // the root is the node to visit next; the stack is empty
+                    sp = 0; mesh_node = obj;
+                    noted = true;
+                }
+            }
+        }
+        if (mine && active && !stopped) node_i = S.n_tlas; // through with the objects
+        if (mine && active && noted) in_bvh = true; // the walk of the mesh noted on the way
+        else if (mine && active && !in_bvh) { // nothing left to look at
+            if (any_hit) shadow_done(io, false);
+            else { finished = true; active = false; }
+        }
+    }
+
     // The scene pass, if enough lanes wait for it, then BVH steps while enough lanes are inside a mesh.
     // Called by the whole wave; every call makes progress if any lane has a ray.
     RT_DEV void phases(const DScene &S, const IO &io, const LaneStack &st, const f4 *top4, PathTally &pt, Tally<COUNT> &tl)
@@ -205,7 +271,12 @@ template <bool COUNT, int LEVELS, class IO> struct RayWalker {
     // scalar fetch; a lane takes part from the node it has got to (the local rays of the hierarchy levels above it
     // are rebuilt on the way there), and stays in the pass until it enters a mesh or runs off the end of the list.
     const uint64_t stepping = __ballot(active && !in_bvh);
-    if (stepping != 0 && ((uint32_t)__popcll(stepping) >= (uint32_t)RT_RAYS_SCENE_MIN_LANES || !__any(in_bvh))) {
+    const bool pass_now = stepping != 0 && ((uint32_t)__popcll(stepping) >= (uint32_t)RT_RAYS_SCENE_MIN_LANES || !__any(in_bvh));
+    if (pass_now && kObjectHierarchy && S.n_tlas > 0) {
+        pt.tock(12);
+        scene_pass_hierarchy(S, io, tl);
+        pt.ran(1, stepping);
+    } else if (pass_now) {
         pt.tock(12);
         const bool mine = active && !in_bvh;
         const int first = node_i;
@@ -386,7 +457,7 @@ template <bool COUNT, int LEVELS, class IO> struct RayWalker {
         if (in_bvh && !at_leaf && cur == kNoNode && sp == 0) { // mesh done: fold its result into the ray's (main.cpp:38-48 / 80-85)
             in_bvh = false;
             if (!kDeferMesh) node_i = mesh_node + 1; // (deferred entry: the pass has moved node_i on already)
-            const bool through = node_i >= S.n_nodes;
+            const bool through = node_i >= ((kObjectHierarchy && S.n_tlas > 0) ? S.n_tlas : S.n_nodes);
             if (any_hit) {
                 if (m_hit) shadow_done(io, true);
                 else if (through) shadow_done(io, false);

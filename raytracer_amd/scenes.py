@@ -235,6 +235,43 @@ def lights_scene_xml(width=96, height=54, grid=3):
     return xml.replace("  </scene>", more + "  </scene>", 1)
 
 
+def mesh_and_spheres_scene_xml(obj_names=("mesh_a.obj", "mesh_b.obj"), grid=8, width=160, height=90, seed=77):
+    """Triangle meshes among many objects: the height field twice (the second one smaller, turned and lifted, so that
+    rays meet two meshes), grid*grid small spheres hovering over them, a floor.  For the scene walks that look at
+    objects through the hierarchy over their boxes."""
+    rng = _PCG32(seed)
+    out = ["<xml>", "  <scene>",
+           f'    <object type="obj" name="{obj_names[0]}" material="smooth"/>',
+           f'    <object type="obj" name="{obj_names[1]}" material="m3"><scale value="0.5"/><rotate angle="35" z="1"/>'
+           '<translate x="4" y="-6" z="7"/></object>',
+           '    <object type="plane" name="floor" material="wall"><scale value="60"/><translate z="-4"/></object>']
+    half = (grid - 1) / 2.0
+    for iy in range(grid):
+        for ix in range(grid):
+            r = 0.3 + 0.5 * rng.f32()
+            m = int(8 * rng.f32())
+            z = 4.0 + 3.0 * rng.f32()
+            out.append(f'    <object type="sphere" name="s{iy}_{ix}" material="m{m}"><scale value="{r:.9g}"/>'
+                       f'<translate x="{(ix - half) * 4.2:.9g}" y="{(iy - half) * 2.2:.9g}" z="{z:.9g}"/></object>')
+    out.append('    <material type="blinn" name="wall"><diffuse value="0.7"/><specular value="0"/></material>')
+    out.append('    <material type="blinn" name="smooth"><diffuse value="0.7"/><specular value="0.3"/><glossiness value="64"/></material>')
+    for i, p in enumerate(_PRESETS):
+        kd = p["kd"]
+        t = [f'    <material type="blinn" name="m{i}">', f'<diffuse r="{kd[0]:.9g}" g="{kd[1]:.9g}" b="{kd[2]:.9g}"/>',
+             f'<specular value="{p["ks"]:.9g}"/><glossiness value="{p["g"]}"/>']
+        if "kr" in p:
+            t.append(f'<reflection value="{p["kr"]:.9g}"/>')
+        if "kt" in p:
+            t.append(f'<refraction value="{p["kt"]:.9g}" index="{p["ior"]:.9g}"/>')
+        t.append("</material>")
+        out.append("".join(t))
+    out += ['    <light type="point" name="pointLight"><intensity value="2500"/><position x="0" y="0" z="30"/><size value="1"/></light>',
+            "  </scene>", '  <camera gamma="sRGB">', '    <position x="0" y="-45" z="22"/>', '    <target x="0" y="0" z="0"/>',
+            '    <up x="0" y="0" z="1"/>', '    <fov value="40"/>', f'    <width value="{width}"/>', f'    <height value="{height}"/>',
+            "  </camera>", "</xml>", ""]
+    return "\n".join(out)
+
+
 def nested_scene_xml(width=320, height=180):
     """Small closed room built from a two-level node hierarchy with rotations,
     non-uniform scales and a thin-lens camera; exercises every transform path."""

@@ -663,6 +663,14 @@ def test_object_hierarchy_changes_nothing(monkeypatch, tmp_path):
     ]
     # ... and the path kernel on the scenes without a mesh (a scene with one goes through the ray-list kernel)
     cases += [(cases[0][0], -50, 4), (cases[2][0], -50, 4), (cases[3][0], -50, 8)]
+    # ... and the ray-list kernel's scene pass: two meshes among 64 spheres (rays that meet both meshes come back to the
+    # pass after the first walk), through the path tracer (wavefront pipeline) and the Whitted-style shader
+    many = lib.HostScene.from_string(scenes.mesh_and_spheres_scene_xml(grid=8, width=160, height=90))
+    mesh = scenes.heightfield(nx=32, ny=16)
+    for name in ("mesh_a.obj", "mesh_b.obj"):
+        many.set_mesh(name, mesh["v"], mesh["vt"], mesh["f"])
+    assert many.desc.n_nodes >= 68
+    cases += [(many, -50, 4), (many, 3, 2), (multi_material_scene(O.load_golden("whitted_multimtl_96x54_b5"), tmp_path), -6, 4)]
     frames = {}
     for tlas_min in ("0", "1"):
         monkeypatch.setenv("RT_TLAS_MIN", tlas_min)
