@@ -55,15 +55,43 @@ RT_DEV void tri_box(const float *v, const uint32_t *f, uint32_t face, float *b)
     }
 }
 
-// Morton code of every face's box centre inside the mesh's bounds
-__global__ __launch_bounds__(kBlock) void k_lbvh_keys(LbvhArrays A, float lo_x, float lo_y, float lo_z, float sx, float sy, float sz)
+// Sort key of every face: the cell of its box centre inside the mesh's bounds (21 bits per axis), the bits of the three
+// axes interleaved in the order `axes` gives, most significant first (2 bits per key bit, bit 0 of the key's top bit in
+// axes[0]).  A plain Morton code takes x, y, z in turn whatever the shape of the mesh; for a mesh that is flat along one
+// axis every third split then cuts a slab that needs no cutting, and the tree comes out a third deeper than the
+// reference's, which splits the widest axis of each node (src/cyCore/cyBVH.h:242-260).  The host deals the bits the
+// same way, once for the whole mesh: always the axis whose cells are still the widest (lbvh_axis_order).
+struct LbvhAxes { unsigned long long w[2]; };
+RT_HD LbvhAxes lbvh_axis_order(const float extent[3])
+{
+    LbvhAxes o{{0ull, 0ull}};
+    float size[3] = {extent[0], extent[1], extent[2]};
+    int left[3] = {21, 21, 21};
+    for (int i = 0; i < 63; ++i) {
+        int a = -1;
+        for (int k = 0; k < 3; ++k) if (left[k] > 0 && (a < 0 || size[k] > size[a])) a = k;
+        size[a] *= 0.5f; --left[a];
+        o.w[i / 32] |= (unsigned long long)a << (2 * (i % 32));
+    }
+    return o;
+}
+__global__ __launch_bounds__(kBlock) void k_lbvh_keys(LbvhArrays A, float lo_x, float lo_y, float lo_z, float sx, float sy, float sz, LbvhAxes axes)
 {
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < A.n; i += gridDim.x * kBlock) {
         float b[6];
         tri_box(A.v, A.f, i, b);
         const float cx = (0.5f * (b[0] + b[3]) - lo_x) * sx, cy = (0.5f * (b[1] + b[4]) - lo_y) * sy, cz = (0.5f * (b[2] + b[5]) - lo_z) * sz;
         const auto cell = [](float c) { return (uint32_t)fminf(fmaxf(c, 0.0f), 2097151.0f); };
-        A.keys[i] = (spread21(cell(cx)) << 2) | (spread21(cell(cy)) << 1) | spread21(cell(cz));
+        // the cells with their top bit at bit 31, so that the next bit to deal is always the sign bit
+        uint32_t c[3] = {cell(cx) << 11, cell(cy) << 11, cell(cz) << 11};
+        unsigned long long key = 0;
+        for (int k = 0; k < 63; ++k) {
+            const uint32_t a = (uint32_t)(axes.w[k / 32] >> (2 * (k % 32))) & 3u;
+            const uint32_t v = a == 0 ? c[0] : a == 1 ? c[1] : c[2];
+            key = (key << 1) | (v >> 31);
+            c[0] = a == 0 ? c[0] << 1 : c[0]; c[1] = a == 1 ? c[1] << 1 : c[1]; c[2] = a == 2 ? c[2] << 1 : c[2];
+        }
+        A.keys[i] = key;
         A.order[i] = i;
     }
 }

@@ -204,7 +204,10 @@ template <bool COUNT, int LEVELS, class IO> struct RayWalker {
     // the records: a lane that comes back from a mesh (it had met a second one) goes on from there - on the way down
     // to its place it follows the records that contain it and looks at nothing else.  (Not the counting variant: the
     // reference tests every object, and the counters are the reference's.)
-    static constexpr bool kObjectHierarchy = !COUNT;
+    // The two passes are separate instantiations (LEVELS == 0: the hierarchy): both in one kernel cost the walker the
+    // registers it has to spare (spills, 12 % on the 1M-triangle frame, which has five objects and never takes it).
+    static constexpr bool kObjectHierarchy = LEVELS == 0;
+    static_assert(!(COUNT && LEVELS == 0), "the counting variant walks the flat list");
     RT_DEV void scene_pass_hierarchy(const DScene &S, const IO &io, Tally<COUNT> &tl)
     {
         const bool mine = active && !in_bvh;
@@ -265,17 +268,19 @@ template <bool COUNT, int LEVELS, class IO> struct RayWalker {
     RT_DEV void phases(const DScene &S, const IO &io, const LaneStack &st, const f4 *top4, PathTally &pt, Tally<COUNT> &tl)
     {
         const float epsilon = 1e-6f;
-        const GF4 bvh = (GF4)S.bvh_pool, tris = (GF4)S.tri_pool;
+        const GF4 bvh = (GF4)S.bvh_pool, tris = (GF4)(kWide ? S.tri4_pool : S.tri_pool);
     // ================= scene-graph steps of rays that are not inside a mesh (main.cpp:16-89) =================
     // One pass over the node list in step: the node index is wave-uniform, so a node's record arrives through one
     // scalar fetch; a lane takes part from the node it has got to (the local rays of the hierarchy levels above it
     // are rebuilt on the way there), and stays in the pass until it enters a mesh or runs off the end of the list.
     const uint64_t stepping = __ballot(active && !in_bvh);
     const bool pass_now = stepping != 0 && ((uint32_t)__popcll(stepping) >= (uint32_t)RT_RAYS_SCENE_MIN_LANES || !__any(in_bvh));
-    if (pass_now && kObjectHierarchy && S.n_tlas > 0) {
-        pt.tock(12);
-        scene_pass_hierarchy(S, io, tl);
-        pt.ran(1, stepping);
+    if constexpr (kObjectHierarchy) {
+        if (pass_now) {
+            pt.tock(12);
+            scene_pass_hierarchy(S, io, tl);
+            pt.ran(1, stepping);
+        }
     } else if (pass_now) {
         pt.tock(12);
         const bool mine = active && !in_bvh;
@@ -457,7 +462,7 @@ template <bool COUNT, int LEVELS, class IO> struct RayWalker {
         if (in_bvh && !at_leaf && cur == kNoNode && sp == 0) { // mesh done: fold its result into the ray's (main.cpp:38-48 / 80-85)
             in_bvh = false;
             if (!kDeferMesh) node_i = mesh_node + 1; // (deferred entry: the pass has moved node_i on already)
-            const bool through = node_i >= ((kObjectHierarchy && S.n_tlas > 0) ? S.n_tlas : S.n_nodes);
+            const bool through = node_i >= (kObjectHierarchy ? S.n_tlas : S.n_nodes);
             if (any_hit) {
                 if (m_hit) shadow_done(io, true);
                 else if (through) shadow_done(io, false);

@@ -91,6 +91,7 @@ struct DScene {
     // of bvh_pool - the grandchildren of a node of the binary tree (a child that is a leaf stands for itself).  The
     // data word of an inner node is the index of its own record; unused places hold boxes no ray enters and kNoNode.
     const float4 *bvh4_pool;
+    const float4 *tri4_pool;   // triangle records in the leaf order of the four-wide BVH (the same array as tri_pool when both forms are one tree)
     const DMesh *meshes;
     const rt_material *materials;
     const rt_light *lights;

@@ -98,6 +98,7 @@ struct rt_ctx {
     int pipeline = -1; // RT_PIPELINE: 0 = lock-step path kernel (k_paths), 1 = wavefront; -1: chosen per scene (wavefront when it has meshes)
     size_t ovf_threads = 0;
     bool query_wide = false;  // RT_QUERY_WIDE=1: rt_trace_brief goes through the four-wide walk of the frames' rays (a test gate; the answers may differ from the reference's in the last bit of t)
+    bool wide_from_gpu = true; // RT_WIDE_GPU_BVH=0: the four-wide BVH of the frames' rays is the reference's binary tree collapsed, not a tree of its own built on the GPU
     bool gpu_bvh = false;     // RT_GPU_BVH=1: build every mesh's BVH on the GPU even if the scene brings one
     double bvh_build_ms = 0;  // GPU time of the last upload's BVH builds
     int tlas_min_objects = 16; // RT_TLAS_MIN: object nodes from which a scene gets the hierarchy over their boxes (0 = never).  The reference's own scene (nine objects, five of them the walls of a box every ray is inside of) is slower through it: 38 -> 56 ms per frame
@@ -255,8 +256,10 @@ const void *whitted_kernel(bool counting, int ray_levels)
     return counting ? (const void *)k_whitted<true, 5> : (const void *)k_whitted<false, 5>;
 }
 
+// ray_levels 0: the scene is walked through the hierarchy over its objects' boxes (scene_levels() below says when)
 const void *rays_kernel(bool counting, int ray_levels)
 {
+    if (ray_levels == 0) return (const void *)k_rays<false, 0, RayListIO>;
     if (ray_levels <= 1) return counting ? (const void *)k_rays<true, 1, RayListIO> : (const void *)k_rays<false, 1, RayListIO>;
     if (ray_levels == 2) return counting ? (const void *)k_rays<true, 2, RayListIO> : (const void *)k_rays<false, 2, RayListIO>;
     return counting ? (const void *)k_rays<true, 5, RayListIO> : (const void *)k_rays<false, 5, RayListIO>;
@@ -265,6 +268,7 @@ const void *rays_kernel(bool counting, int ray_levels)
 // rt_trace_brief through the four-wide walk (RT_QUERY_WIDE=1; the counting variant always walks the binary tree)
 const void *rays_kernel_wide(int ray_levels)
 {
+    if (ray_levels == 0) return (const void *)k_rays<false, 0, RayListWideIO>;
     if (ray_levels <= 1) return (const void *)k_rays<false, 1, RayListWideIO>;
     if (ray_levels == 2) return (const void *)k_rays<false, 2, RayListWideIO>;
     return (const void *)k_rays<false, 5, RayListWideIO>;
@@ -272,10 +276,15 @@ const void *rays_kernel_wide(int ray_levels)
 
 const void *wf_trace_kernel(bool counting, int ray_levels)
 {
+    if (ray_levels == 0) return (const void *)k_rays<false, 0, WfIO>;
     if (ray_levels <= 1) return counting ? (const void *)k_rays<true, 1, WfIO> : (const void *)k_rays<false, 1, WfIO>;
     if (ray_levels == 2) return counting ? (const void *)k_rays<true, 2, WfIO> : (const void *)k_rays<false, 2, WfIO>;
     return counting ? (const void *)k_rays<true, 5, WfIO> : (const void *)k_rays<false, 5, WfIO>;
 }
+
+// which instantiation of the ray-list kernels a scene takes: the one that walks the object hierarchy if the scene has one
+// (not the counting variant: its box and triangle tests are the reference's, which looks at every object)
+int scene_levels(const rt_ctx *ctx) { return (!ctx->counting && ctx->scene.n_tlas > 0) ? 0 : ctx->ray_levels; }
 
 size_t stack_lds_bytes(const DScene &S) { return (size_t)S.lds_levels * kBlock * 8; }
 // kernels that look photons up keep the arrays of found photons of kGatherSlots lanes per wave behind the stacks
@@ -326,7 +335,7 @@ static int render_wavefront(rt_ctx *ctx, const DFrame &F, const int32_t *act, ui
     hipLaunchKernelGGL(k_wf_generate, wide, dim3(kBlock), 0, s, F, ctx->d_halton.as<float>(), act, items, k0, nk, P, cnt);
     HIP_TRY(ctx, hipGetLastError());
 
-    const void *fn = wf_trace_kernel(ctx->counting, ctx->ray_levels);
+    const void *fn = wf_trace_kernel(ctx->counting, scene_levels(ctx));
     int per_cu = 1;
     const size_t lds_rays = lds + (ctx->counting ? 0 : (size_t)ctx->scene.top4_count * 128); // the top of the wide BVH behind the stacks
     HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kBlock, lds_rays));
@@ -379,7 +388,7 @@ static int render_wavefront(rt_ctx *ctx, const DFrame &F, const int32_t *act, ui
         if (finishing) { // the shadow rays of the last shaded bounce, then the remaining paths to their ends in one launch
             if (h.n_shadow > 0) if (int rc = launch_rays(b, queue_in, h.n_shadow, true)) return rc;
             const void *ff = ctx->counting ? (ctx->ray_levels <= 1 ? (const void *)k_wf_finish<true, 1> : ctx->ray_levels == 2 ? (const void *)k_wf_finish<true, 2> : (const void *)k_wf_finish<true, 5>)
-                                           : (ctx->ray_levels <= 1 ? (const void *)k_wf_finish<false, 1> : ctx->ray_levels == 2 ? (const void *)k_wf_finish<false, 2> : (const void *)k_wf_finish<false, 5>);
+                                           : (scene_levels(ctx) == 0 ? (const void *)k_wf_finish<false, 0> : ctx->ray_levels <= 1 ? (const void *)k_wf_finish<false, 1> : ctx->ray_levels == 2 ? (const void *)k_wf_finish<false, 2> : (const void *)k_wf_finish<false, 5>);
             // a pair of lanes per path
             const dim3 grid((unsigned)std::min<uint64_t>((n_live * 2 + kBlock - 1) / kBlock, ctx->ovf_threads / kBlock));
             DFrame f_frame = F;
@@ -520,6 +529,9 @@ int rt_init(int device, rt_ctx **out)
                           (const void *)k_order_keys<1>, (const void *)k_order_keys<2>, (const void *)k_order_keys<5>,
                           (const void *)k_trace, (const void *)k_trace_shadow, (const void *)k_trace_paths})
         (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynamicLds);
+    for (const void *k : {(const void *)k_rays<false, 0, RayListIO>, (const void *)k_rays<false, 0, RayListWideIO>, (const void *)k_rays<false, 0, WfIO>,
+                          (const void *)k_rays<false, 0, BriefIO>, (const void *)k_wf_finish<false, 0>})
+        (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynamicLds);
     for (const void *k : {(const void *)k_rays<false, 1, BriefIO>, (const void *)k_rays<false, 2, BriefIO>, (const void *)k_rays<false, 5, BriefIO>,
                           (const void *)k_rays<false, 1, RayListWideIO>, (const void *)k_rays<false, 2, RayListWideIO>, (const void *)k_rays<false, 5, RayListWideIO>})
         (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynamicLds);
@@ -540,6 +552,7 @@ int rt_init(int device, rt_ctx **out)
     if (const char *e7 = getenv("RT_ORDER")) ctx->order_pixels = atoi(e7) != 0 ? 1 : 0;
     if (const char *e11 = getenv("RT_GPU_BVH")) ctx->gpu_bvh = atoi(e11) != 0;
     if (const char *e12 = getenv("RT_QUERY_WIDE")) ctx->query_wide = atoi(e12) != 0;
+    if (const char *e14 = getenv("RT_WIDE_GPU_BVH")) ctx->wide_from_gpu = atoi(e14) != 0;
     if (const char *e13 = getenv("RT_WF_REPLAY")) ctx->wf_replay = atoi(e13) != 0;
     if (const char *e10 = getenv("RT_TLAS_MIN")) ctx->tlas_min_objects = std::max(0, atoi(e10));
     if (const char *e2 = getenv("RT_LDS_LEVELS")) ctx->lds_levels_max = std::max(1, std::min(64, atoi(e2))); // tuning knob
@@ -623,7 +636,13 @@ static int build_bvh_gpu(rt_ctx *ctx, const rt_mesh &m, uint32_t node_base, uint
     A.depth = depth.as<uint32_t>(); A.record = record.as<uint32_t>(); A.max_depth = maxd.as<uint32_t>();
     const dim3 grid((unsigned)std::min<size_t>(((size_t)n + kBlock - 1) / kBlock, (size_t)ctx->n_cu * 16)), block(kBlock);
     const auto scale = [&](int a) { return hi[a] > lo[a] ? 2097151.0f / (hi[a] - lo[a]) : 0.0f; };
-    hipLaunchKernelGGL(k_lbvh_keys, grid, block, 0, s, A, lo[0], lo[1], lo[2], scale(0), scale(1), scale(2));
+    const float extent[3] = {hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
+    LbvhAxes axes = lbvh_axis_order(extent);
+    if (getenv("RT_LBVH_PLAIN_MORTON")) { // (for comparison: x, y, z in turn)
+        axes = LbvhAxes{{0ull, 0ull}};
+        for (int i = 0; i < 63; ++i) axes.w[i / 32] |= (unsigned long long)(i % 3) << (2 * (i % 32));
+    }
+    hipLaunchKernelGGL(k_lbvh_keys, grid, block, 0, s, A, lo[0], lo[1], lo[2], scale(0), scale(1), scale(2), axes);
     size_t tmp_bytes = 0;
     HIP_TRY(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys[0].as<unsigned long long>(), keys[1].as<unsigned long long>(),
                                            order[0].as<uint32_t>(), order[1].as<uint32_t>(), (size_t)n, 0u, 63u, s));
@@ -756,7 +775,13 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc)
     // A scene whose meshes come without a BVH (or RT_GPU_BVH=1) gets them built here, on the GPU (device/lbvh.h)
     bool gpu_bvh = ctx->gpu_bvh;
     for (uint32_t mi = 0; mi < sc->n_meshes; ++mi) gpu_bvh = gpu_bvh || !sc->meshes[mi].bvh_nodes || !sc->meshes[mi].bvh_elements;
-    std::vector<GpuBvh> built(gpu_bvh ? sc->n_meshes : 0);
+    // A scene that brings the reference's BVH keeps it for everything that has to give the reference's answers and
+    // counts (depth / id planes, query entry points, the counting variant).  The frames' extension and shadow rays,
+    // which go through the four-wide walk and are held to the image tolerance, get a tree of their own, built here on
+    // the GPU: it holds the same triangles under the same test, and is the better tree (device/lbvh.h: frames of the
+    // 1M-triangle scene take 7 % less through it than through the reference's tree collapsed to four-wide records).
+    const bool wide_gpu = !gpu_bvh && ctx->wide_from_gpu && sc->n_meshes > 0;
+    std::vector<GpuBvh> built(gpu_bvh || wide_gpu ? sc->n_meshes : 0);
     size_t pool_recs = 0;
     double build_ms = 0;
     for (uint32_t mi = 0; mi < sc->n_meshes; ++mi) {
@@ -772,8 +797,17 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc)
             pool_nodes += built[mi].n_nodes;
             pool_recs += built[mi].n_recs;
             build_ms += built[mi].ms;
-        } else
-        pool_nodes += ((size_t)m.n_bvh_nodes + 1) / 2 * 2;
+        } else {
+            pool_nodes += ((size_t)m.n_bvh_nodes + 1) / 2 * 2;
+            if (wide_gpu) {
+                if (m.nf >= (1u << 28)) return ctx->fail(RT_ERR_UNSUPPORTED, "scene has more than 2^28 triangles");
+                for (size_t k = 0; k < (size_t)m.nf * 3; ++k)
+                    if (m.f[k] >= m.nv) return ctx->fail(RT_ERR_INVALID, "mesh %u: face index out of range", mi);
+                if (int rc = build_bvh_gpu(ctx, m, 0u, (uint32_t)pool_recs, tri_base[mi], built[mi])) return rc; // (its binary nodes are not kept)
+                pool_recs += built[mi].n_recs;
+                build_ms += built[mi].ms;
+            }
+        }
         pool_tris += m.nf;
         if (pool_nodes >= ((size_t)1 << 31) || pool_tris >= ((size_t)1 << 28)) return ctx->fail(RT_ERR_UNSUPPORTED, "scene has more than 2^28 triangles");
     }
@@ -831,7 +865,10 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc)
             if (id == 1) { roots[mi] = b; roots[mi].data = data; }
         }
         // the four-wide form: a record per inner node reached in steps of two levels from the root
-        {
+        if (wide_gpu) { // (the frames' rays have a tree of their own, built above)
+            root4[mi] = built[mi].root4;
+            depth = std::max(depth, built[mi].depth);
+        } else {
             const auto pooled = [&](uint32_t id) { return __builtin_bit_cast(uint32_t, bvh[(size_t)(nb + id) * 2 + 1].z); }; // data word, pool numbering
             const auto is_leaf = [&](uint32_t id) { return (m.bvh_nodes[id].data & 0x80000000u) != 0; };
             const float inf = std::numeric_limits<float>::infinity();
@@ -892,7 +929,7 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc)
             any_face_materials = true;
         }
     }
-    const float4 *d_bvh_pool = nullptr, *d_tri_pool = nullptr, *d_bvh4_pool = nullptr;
+    const float4 *d_bvh_pool = nullptr, *d_tri_pool = nullptr, *d_bvh4_pool = nullptr, *d_tri4_pool = nullptr;
     if (sc->n_meshes && gpu_bvh) { // the meshes' parts, each built in pool numbering, side by side in the three pools
         auto pool = [&](size_t bytes, const void **dst) -> hipError_t {
             auto b = std::make_unique<DeviceBuf>();
@@ -915,14 +952,37 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc)
             g.nodes.reset(); g.recs.reset(); g.tris.reset();
         }
         for (DMesh &d : dmeshes) { d.bvh = d_bvh_pool; d.tris = d_tri_pool; }
+        d_tri4_pool = d_tri_pool;
         ctx->bvh_build_ms = build_ms;
     } else if (sc->n_meshes) {
-        if (bvh4.empty()) bvh4.resize(8, make_float4(0, 0, 0, 0));
-        HIP_TRY(ctx, upload(bvh4.data(), bvh4.size() * sizeof(float4), (const void **)&d_bvh4_pool));
         HIP_TRY(ctx, upload(bvh.data(), bvh.size() * sizeof(float4), (const void **)&d_bvh_pool));
         HIP_TRY(ctx, upload(tris.data(), tris.size() * sizeof(float4), (const void **)&d_tri_pool));
         for (DMesh &d : dmeshes) { d.bvh = d_bvh_pool; d.tris = d_tri_pool; }
-        ctx->bvh_build_ms = 0;
+        if (wide_gpu) { // the four-wide records and the triangle records in their leaf order, mesh after mesh
+            auto pool = [&](size_t bytes, const void **dst) -> hipError_t {
+                auto b = std::make_unique<DeviceBuf>();
+                hipError_t e = b->reserve(std::max<size_t>(128, bytes));
+                *dst = b->p;
+                bufs.push_back(std::move(b));
+                return e;
+            };
+            HIP_TRY(ctx, pool(pool_recs * 128, (const void **)&d_bvh4_pool));
+            HIP_TRY(ctx, pool(pool_tris * 48, (const void **)&d_tri4_pool));
+            size_t rec_at = 0;
+            for (uint32_t mi = 0; mi < sc->n_meshes; ++mi) {
+                GpuBvh &g = built[mi];
+                if (g.n_recs) HIP_TRY(ctx, hipMemcpy((char *)d_bvh4_pool + rec_at * 128, g.recs->p, (size_t)g.n_recs * 128, hipMemcpyDeviceToDevice));
+                HIP_TRY(ctx, hipMemcpy((char *)d_tri4_pool + (size_t)tri_base[mi] * 48, g.tris->p, (size_t)sc->meshes[mi].nf * 48, hipMemcpyDeviceToDevice));
+                rec_at += g.n_recs;
+                g.nodes.reset(); g.recs.reset(); g.tris.reset();
+            }
+            ctx->bvh_build_ms = build_ms;
+        } else {
+            if (bvh4.empty()) bvh4.resize(8, make_float4(0, 0, 0, 0));
+            HIP_TRY(ctx, upload(bvh4.data(), bvh4.size() * sizeof(float4), (const void **)&d_bvh4_pool));
+            d_tri4_pool = d_tri_pool;
+            ctx->bvh_build_ms = 0;
+        }
     }
     // compact node records of the ray-list kernel
     std::vector<TNode> tnodes(nn);
@@ -1063,7 +1123,7 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc)
     if (!tlas.empty()) HIP_TRY(ctx, hipMemcpy(ctx->d_tlas.p, tlas.data(), sizeof(TlasNode) * tlas.size(), hipMemcpyHostToDevice));
     S.tlas = tlas.empty() ? nullptr : ctx->d_tlas.as<TlasNode>();
     S.n_tlas = (int32_t)tlas.size();
-    S.bvh_pool = d_bvh_pool; S.tri_pool = d_tri_pool; S.bvh4_pool = d_bvh4_pool;
+    S.bvh_pool = d_bvh_pool; S.tri_pool = d_tri_pool; S.bvh4_pool = d_bvh4_pool; S.tri4_pool = d_tri4_pool;
     S.top4_base = top4_base; S.top4_count = top4_count;
     S.cancel = (const uint32_t *)&ctx->host_words[0];
     S.progress = &ctx->host_words[1];
@@ -1521,7 +1581,7 @@ int rt_trace_brief(rt_ctx *ctx, const float *rays6, const float *t_max, int n, r
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_q_in.p, od.data(), (size_t)n * 32, hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters.p, 0, sizeof(DCounters), s));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue.p, 0, kQueueBytes, s));
-    const void *fn = ctx->query_wide && !ctx->counting ? rays_kernel_wide(ctx->ray_levels) : rays_kernel(ctx->counting, ctx->ray_levels);
+    const void *fn = ctx->query_wide && !ctx->counting ? rays_kernel_wide(scene_levels(ctx)) : rays_kernel(ctx->counting, scene_levels(ctx));
     const size_t lds = stack_lds_bytes(ctx->scene);
     int per_cu = 1;
     HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kBlock, lds));
@@ -1580,7 +1640,8 @@ int rt_trace_brief_noalloc(rt_ctx *ctx, const float *d_rays6, const float *d_t_m
     const size_t ovf_levels = std::max<size_t>(1, (size_t)(S0.stack_levels - S0.lds_levels));
     const size_t max_blocks = kStaticStackEntries / (ovf_levels * kBlock);
     if (max_blocks < 1) return ctx->fail(RT_ERR_UNSUPPORTED, "rt_trace_brief_noalloc: %zu stack levels beyond LDS exceed the static scratch", ovf_levels);
-    const void *fn = ctx->ray_levels <= 1 ? (const void *)k_rays<false, 1, BriefIO> : ctx->ray_levels == 2 ? (const void *)k_rays<false, 2, BriefIO> : (const void *)k_rays<false, 5, BriefIO>;
+    const void *fn = ctx->scene.n_tlas > 0 ? (const void *)k_rays<false, 0, BriefIO>
+                     : ctx->ray_levels <= 1 ? (const void *)k_rays<false, 1, BriefIO> : ctx->ray_levels == 2 ? (const void *)k_rays<false, 2, BriefIO> : (const void *)k_rays<false, 5, BriefIO>;
     const size_t lds = stack_lds_bytes(ctx->scene);
     int per_cu = 1;
     HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kBlock, lds));
