@@ -15,12 +15,17 @@
 namespace rtd {
 
 constexpr uint32_t kLbvhLeaf = 0x80000000u; // child word: a sorted triangle position, not an internal node
-constexpr uint32_t kLbvhMaxLeafTris = 4;
+// Triangles per leaf.  A tree that stands in for the reference's (a scene without a BVH: depth / id planes, queries and
+// counters go through it too) takes the reference's four (src/objects.h:63); the tree the frames' four-wide walk gets
+// for itself takes two: a leaf visit tests two triangles at a time, and with two per leaf the 1M-triangle frame takes
+// 76.8 ms against 79.5 with four (81.5 with one, 77.9 with three, 84.2 with eight).
+constexpr uint32_t kLbvhMaxLeafTris = 4, kLbvhWideLeafTris = 2;
 
 struct LbvhArrays {
     const float *v;          // positions, 3 floats each
     const uint32_t *f;       // 3 position indices per face
     uint32_t n;              // faces
+    uint32_t max_leaf;       // triangles a leaf may hold
     unsigned long long *keys; // Morton codes, sorted
     uint32_t *order;         // face of sorted position k
     uint2 *child;            // [n - 1] children of internal node i (kLbvhLeaf: sorted position)
@@ -29,7 +34,7 @@ struct LbvhArrays {
     uint2 *range;            // [n - 1] first and last sorted position under internal node i
     float *ibox, *lbox;      // [n - 1][6], [n][6]: min xyz, max xyz
     uint32_t *arrived;       // [n - 1] children that have reported their boxes
-    uint32_t *inner;         // [n - 1] 1: more than kLbvhMaxLeafTris triangles below (stays an inner node); then its rank among those
+    uint32_t *inner;         // [n - 1] 1: more than max_leaf triangles below (stays an inner node); then its rank among those
     uint32_t *depth;         // [n - 1] levels above a kept inner node
     uint32_t *record;        // [n - 1] 1: gets a four-wide record (kept inner node at even depth); then its rank among those
     uint32_t *max_depth;     // [1]
@@ -164,12 +169,12 @@ __global__ __launch_bounds__(kBlock) void k_lbvh_fit(LbvhArrays A)
     }
 }
 
-// which internal nodes stay inner nodes (more than four triangles below)
+// which internal nodes stay inner nodes (more triangles below than a leaf may hold)
 __global__ __launch_bounds__(kBlock) void k_lbvh_mark_inner(LbvhArrays A)
 {
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i + 1 < A.n; i += gridDim.x * kBlock) {
         const uint2 r = A.range[i];
-        A.inner[i] = r.y - r.x + 1 > kLbvhMaxLeafTris ? 1u : 0u;
+        A.inner[i] = r.y - r.x + 1 > A.max_leaf ? 1u : 0u;
     }
 }
 

@@ -602,7 +602,7 @@ struct GpuBvh {
     double ms = 0;
 };
 
-static int build_bvh_gpu(rt_ctx *ctx, const rt_mesh &m, uint32_t node_base, uint32_t rec_base, uint32_t tri_base, GpuBvh &out)
+static int build_bvh_gpu(rt_ctx *ctx, const rt_mesh &m, uint32_t node_base, uint32_t rec_base, uint32_t tri_base, uint32_t max_leaf, GpuBvh &out)
 {
     hipStream_t s = ctx->stream;
     const uint32_t n = m.nf;
@@ -629,7 +629,7 @@ static int build_bvh_gpu(rt_ctx *ctx, const rt_mesh &m, uint32_t node_base, uint
     HIP_TRY(ctx, hipMemsetAsync(maxd.p, 0, 4, s));
     HIP_TRY(ctx, hipEventRecord(ctx->evk0, s));
     LbvhArrays A{};
-    A.v = d_v.as<float>(); A.f = d_f.as<uint32_t>(); A.n = n;
+    A.v = d_v.as<float>(); A.f = d_f.as<uint32_t>(); A.n = n; A.max_leaf = max_leaf;
     A.keys = keys[0].as<unsigned long long>(); A.order = order[0].as<uint32_t>();
     A.child = child.as<uint2>(); A.parent = parent.as<uint32_t>(); A.leaf_parent = leaf_parent.as<uint32_t>(); A.range = range.as<uint2>();
     A.ibox = ibox.as<float>(); A.lbox = lbox.as<float>(); A.arrived = arrived.as<uint32_t>(); A.inner = inner.as<uint32_t>();
@@ -655,7 +655,7 @@ static int build_bvh_gpu(rt_ctx *ctx, const rt_mesh &m, uint32_t node_base, uint
     HIP_TRY(ctx, out.tris->reserve((size_t)n * 48));
     O.tris = out.tris->as<float4>();
     uint32_t T = 0, R = 0;
-    if (n > kLbvhMaxLeafTris) {
+    if (n > max_leaf) {
         hipLaunchKernelGGL(k_lbvh_hierarchy, grid, block, 0, s, A);
         hipLaunchKernelGGL(k_lbvh_fit, grid, block, 0, s, A);
         hipLaunchKernelGGL(k_lbvh_mark_inner, grid, block, 0, s, A);
@@ -793,7 +793,7 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc)
             if (m.nf >= (1u << 28)) return ctx->fail(RT_ERR_UNSUPPORTED, "scene has more than 2^28 triangles");
             for (size_t k = 0; k < (size_t)m.nf * 3; ++k)
                 if (m.f[k] >= m.nv) return ctx->fail(RT_ERR_INVALID, "mesh %u: face index out of range", mi);
-            if (int rc = build_bvh_gpu(ctx, m, node_base[mi], (uint32_t)pool_recs, tri_base[mi], built[mi])) return rc;
+            if (int rc = build_bvh_gpu(ctx, m, node_base[mi], (uint32_t)pool_recs, tri_base[mi], kLbvhMaxLeafTris, built[mi])) return rc;
             pool_nodes += built[mi].n_nodes;
             pool_recs += built[mi].n_recs;
             build_ms += built[mi].ms;
@@ -803,7 +803,7 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc)
                 if (m.nf >= (1u << 28)) return ctx->fail(RT_ERR_UNSUPPORTED, "scene has more than 2^28 triangles");
                 for (size_t k = 0; k < (size_t)m.nf * 3; ++k)
                     if (m.f[k] >= m.nv) return ctx->fail(RT_ERR_INVALID, "mesh %u: face index out of range", mi);
-                if (int rc = build_bvh_gpu(ctx, m, 0u, (uint32_t)pool_recs, tri_base[mi], built[mi])) return rc; // (its binary nodes are not kept)
+                if (int rc = build_bvh_gpu(ctx, m, 0u, (uint32_t)pool_recs, tri_base[mi], kLbvhWideLeafTris, built[mi])) return rc; // (its binary nodes are not kept)
                 pool_recs += built[mi].n_recs;
                 build_ms += built[mi].ms;
             }
