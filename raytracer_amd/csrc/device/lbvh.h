@@ -35,8 +35,6 @@ struct LbvhArrays {
     float *ibox, *lbox;      // [n - 1][6], [n][6]: min xyz, max xyz
     uint32_t *arrived;       // [n - 1] children that have reported their boxes
     uint32_t *inner;         // [n - 1] 1: more than max_leaf triangles below (stays an inner node); then its rank among those
-    uint32_t *depth;         // [n - 1] levels above a kept inner node
-    uint32_t *record;        // [n - 1] 1: gets a four-wide record (kept inner node at even depth); then its rank among those
     uint32_t *max_depth;     // [1]
 };
 
@@ -178,7 +176,7 @@ __global__ __launch_bounds__(kBlock) void k_lbvh_mark_inner(LbvhArrays A)
     }
 }
 
-// depth of every kept inner node (its ancestors are kept inner nodes too), which of them get a four-wide record
+// levels of the binary tree: the deepest kept inner node (its ancestors are kept inner nodes too)
 __global__ __launch_bounds__(kBlock) void k_lbvh_depth(LbvhArrays A, const uint32_t *__restrict__ inner_flag)
 {
     uint32_t deepest = 0;
@@ -188,8 +186,6 @@ __global__ __launch_bounds__(kBlock) void k_lbvh_depth(LbvhArrays A, const uint3
             for (uint32_t p = A.parent[i]; p != 0xFFFFFFFFu; p = A.parent[p & 0x7FFFFFFFu]) ++d;
             deepest = d + 1 > deepest ? d + 1 : deepest; // its children are one level further down
         }
-        A.depth[i] = d;
-        A.record[i] = inner_flag[i] && (d & 1u) == 0 ? 1u : 0u;
     }
     if (deepest) atomicMax(A.max_depth, deepest);
 }
@@ -244,35 +240,51 @@ __global__ __launch_bounds__(kBlock) void k_lbvh_emit_binary(LbvhArrays A, const
     }
 }
 
-// the four-wide records: a kept inner node at even depth writes the boxes of its grandchildren (a child that is a
-// leaf stands for itself); an inner grandchild is named by its own record
-__global__ __launch_bounds__(kBlock) void k_lbvh_emit_wide(LbvhArrays A, const uint32_t *__restrict__ inner_flag, const uint32_t *__restrict__ inner_rank,
-                                                           const uint32_t *__restrict__ record_flag, const uint32_t *__restrict__ record_rank, LbvhOut O)
+// The four-wide records, one level of the wide tree per launch, from the root down. A record starts from the two
+// children of its node and twice replaces the widest kept inner node among its slots (largest box area: the one a ray
+// is likeliest to enter) by that node's two children, so a record may reach three levels down one side of the binary
+// tree and one down the other. A slot that is still a kept inner node gets a record of its own on the next level.
+// `front[r]` is the node behind record r; `count[l]` is the number of records on level l, and the records of a level
+// are numbered after all those of the levels above.
+__global__ __launch_bounds__(kBlock) void k_lbvh_wide_level(LbvhArrays A, const uint32_t *__restrict__ inner_flag, const uint32_t *__restrict__ inner_rank,
+                                                            uint32_t *__restrict__ front, uint32_t *__restrict__ count, uint32_t level, LbvhOut O)
 {
     const float inf = __builtin_inff();
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i + 1 < A.n; i += gridDim.x * kBlock) {
-        if (!record_flag[i]) continue;
-        float4 *rec = O.recs + (size_t)record_rank[i] * 8;
-        uint32_t slot = 0;
-        const uint2 c = A.child[i];
-        for (int side = 0; side < 2; ++side) {
-            const uint32_t ch = side ? c.y : c.x;
-            const float *box; bool inner;
-            const uint32_t w = lbvh_child_word(A, inner_rank, inner_flag, ch, O, box, inner);
-            if (!inner) { lbvh_store_node(rec + slot * 2, box, w); ++slot; continue; }
-            const uint2 g = A.child[ch];
-            for (int gs = 0; gs < 2; ++gs) {
-                const uint32_t gc = gs ? g.y : g.x;
-                const float *gbox; bool ginner;
-                uint32_t gw = lbvh_child_word(A, inner_rank, inner_flag, gc, O, gbox, ginner);
-                if (ginner) gw = O.rec_base + record_rank[gc]; // a kept inner node two levels down has a record of its own
-                lbvh_store_node(rec + slot * 2, gbox, gw);
-                ++slot;
+    uint32_t begin = 0;
+    for (uint32_t l = 0; l < level; ++l) begin += count[l];
+    const uint32_t n_here = count[level], next_begin = begin + n_here;
+    for (uint32_t q = blockIdx.x * kBlock + threadIdx.x; q < n_here; q += gridDim.x * kBlock) {
+        const uint32_t r = begin + q;
+        const uint2 c = A.child[front[r]];
+        uint32_t slots[4] = {c.x, c.y, 0, 0}, ns = 2;
+        for (int step = 0; step < 2; ++step) {
+            int widest = -1; float area = -1.0f;
+            for (uint32_t k = 0; k < ns; ++k) {
+                const uint32_t ch = slots[k];
+                if ((ch & kLbvhLeaf) || !inner_flag[ch]) continue;
+                const float *b = A.ibox + (size_t)ch * 6;
+                const float dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2];
+                const float a = dx * dy + dy * dz + dz * dx;
+                if (a > area) { area = a; widest = (int)k; }
             }
+            if (widest < 0) break;
+            const uint2 g = A.child[slots[widest]];
+            slots[widest] = g.x; slots[ns++] = g.y;
         }
-        for (; slot < 4; ++slot) { // boxes no ray enters
-            rec[slot * 2] = make_float4(inf, inf, inf, inf);
-            rec[slot * 2 + 1] = make_float4(inf, inf, __uint_as_float(0x7FFFFFFFu), 0.0f);
+        uint32_t n_inner = 0;
+        for (uint32_t k = 0; k < ns; ++k) n_inner += !(slots[k] & kLbvhLeaf) && inner_flag[slots[k]] ? 1u : 0u;
+        uint32_t next = n_inner ? next_begin + atomicAdd(&count[level + 1], n_inner) : 0u;
+        float4 *rec = O.recs + (size_t)r * 8;
+        for (uint32_t k = 0; k < 4; ++k) {
+            if (k < ns) {
+                const float *box; bool inner;
+                uint32_t w = lbvh_child_word(A, inner_rank, inner_flag, slots[k], O, box, inner);
+                if (inner) { front[next] = slots[k]; w = O.rec_base + next++; }
+                lbvh_store_node(rec + k * 2, box, w);
+            } else { // a box no ray enters
+                rec[k * 2] = make_float4(inf, inf, inf, inf);
+                rec[k * 2 + 1] = make_float4(inf, inf, __uint_as_float(0x7FFFFFFFu), 0.0f);
+            }
         }
     }
 }

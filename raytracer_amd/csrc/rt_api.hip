@@ -597,7 +597,7 @@ int rt_set_counting(rt_ctx *ctx, int on)
 struct GpuBvh {
     std::unique_ptr<DeviceBuf> nodes, recs, tris;
     uint32_t n_nodes = 0, n_recs = 0; // pool entries (binary nodes incl. the unused first two; records)
-    uint32_t root_word = 0, root4 = 0, depth = 0;
+    uint32_t root_word = 0, root4 = 0, depth = 0, wide_levels = 0; // levels of the binary tree, of the four-wide one
     float bounds[6] = {0, 0, 0, 0, 0, 0};
     double ms = 0;
 };
@@ -614,7 +614,7 @@ static int build_bvh_gpu(rt_ctx *ctx, const rt_mesh &m, uint32_t node_base, uint
         for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], q[a]); hi[a] = std::max(hi[a], q[a]); }
     }
     for (int a = 0; a < 3; ++a) { out.bounds[a] = lo[a]; out.bounds[3 + a] = hi[a]; }
-    DeviceBuf d_v, d_f, keys[2], order[2], child, parent, leaf_parent, range, ibox, lbox, arrived, inner, inner_rank, depth, record, record_rank, maxd, tmp;
+    DeviceBuf d_v, d_f, keys[2], order[2], child, parent, leaf_parent, range, ibox, lbox, arrived, inner, inner_rank, front, level_count, maxd, tmp;
     HIP_TRY(ctx, d_v.reserve((size_t)m.nv * 12)); HIP_TRY(ctx, d_f.reserve((size_t)n * 12));
     HIP_TRY(ctx, hipMemcpyAsync(d_v.p, m.v, (size_t)m.nv * 12, hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemcpyAsync(d_f.p, m.f, (size_t)n * 12, hipMemcpyHostToDevice, s));
@@ -624,7 +624,6 @@ static int build_bvh_gpu(rt_ctx *ctx, const rt_mesh &m, uint32_t node_base, uint
     HIP_TRY(ctx, child.reserve(ni * 8)); HIP_TRY(ctx, parent.reserve(ni * 4)); HIP_TRY(ctx, leaf_parent.reserve((size_t)n * 4));
     HIP_TRY(ctx, range.reserve(ni * 8)); HIP_TRY(ctx, ibox.reserve(ni * 24)); HIP_TRY(ctx, lbox.reserve((size_t)n * 24));
     HIP_TRY(ctx, arrived.reserve(ni * 4)); HIP_TRY(ctx, inner.reserve(ni * 4)); HIP_TRY(ctx, inner_rank.reserve(ni * 4));
-    HIP_TRY(ctx, depth.reserve(ni * 4)); HIP_TRY(ctx, record.reserve(ni * 4)); HIP_TRY(ctx, record_rank.reserve(ni * 4));
     HIP_TRY(ctx, maxd.reserve(4));
     HIP_TRY(ctx, hipMemsetAsync(maxd.p, 0, 4, s));
     HIP_TRY(ctx, hipEventRecord(ctx->evk0, s));
@@ -633,7 +632,7 @@ static int build_bvh_gpu(rt_ctx *ctx, const rt_mesh &m, uint32_t node_base, uint
     A.keys = keys[0].as<unsigned long long>(); A.order = order[0].as<uint32_t>();
     A.child = child.as<uint2>(); A.parent = parent.as<uint32_t>(); A.leaf_parent = leaf_parent.as<uint32_t>(); A.range = range.as<uint2>();
     A.ibox = ibox.as<float>(); A.lbox = lbox.as<float>(); A.arrived = arrived.as<uint32_t>(); A.inner = inner.as<uint32_t>();
-    A.depth = depth.as<uint32_t>(); A.record = record.as<uint32_t>(); A.max_depth = maxd.as<uint32_t>();
+    A.max_depth = maxd.as<uint32_t>();
     const dim3 grid((unsigned)std::min<size_t>(((size_t)n + kBlock - 1) / kBlock, (size_t)ctx->n_cu * 16)), block(kBlock);
     const auto scale = [&](int a) { return hi[a] > lo[a] ? 2097151.0f / (hi[a] - lo[a]) : 0.0f; };
     const float extent[3] = {hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
@@ -654,7 +653,7 @@ static int build_bvh_gpu(rt_ctx *ctx, const rt_mesh &m, uint32_t node_base, uint
     O.node_base = node_base; O.rec_base = rec_base; O.tri_base = tri_base;
     HIP_TRY(ctx, out.tris->reserve((size_t)n * 48));
     O.tris = out.tris->as<float4>();
-    uint32_t T = 0, R = 0;
+    uint32_t T = 0, R = 0, deepest = 0;
     if (n > max_leaf) {
         hipLaunchKernelGGL(k_lbvh_hierarchy, grid, block, 0, s, A);
         hipLaunchKernelGGL(k_lbvh_fit, grid, block, 0, s, A);
@@ -673,14 +672,27 @@ static int build_bvh_gpu(rt_ctx *ctx, const rt_mesh &m, uint32_t node_base, uint
         };
         if (int rc = scan(inner, inner_rank, T)) return rc;
         hipLaunchKernelGGL(k_lbvh_depth, grid, block, 0, s, A, inner.as<uint32_t>());
-        if (int rc = scan(record, record_rank, R)) return rc;
-        if ((uint64_t)node_base + 2 + 2ull * T >= (1ull << 31) || (uint64_t)rec_base + R >= (1ull << 31)) return ctx->fail(RT_ERR_UNSUPPORTED, "scene has too many BVH nodes");
-        out.n_nodes = 2 + 2 * T; out.n_recs = R;
-        HIP_TRY(ctx, out.nodes->reserve((size_t)out.n_nodes * 32)); HIP_TRY(ctx, out.recs->reserve(std::max<size_t>(1, (size_t)R * 128)));
+        HIP_TRY(ctx, hipMemcpyAsync(&deepest, maxd.p, 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipStreamSynchronize(s));
+        // every kept inner node could be the root of a record; the wide tree has at most as many levels as the binary one
+        if ((uint64_t)node_base + 2 + 2ull * T >= (1ull << 31) || (uint64_t)rec_base + T >= (1ull << 31)) return ctx->fail(RT_ERR_UNSUPPORTED, "scene has too many BVH nodes");
+        out.n_nodes = 2 + 2 * T;
+        HIP_TRY(ctx, out.nodes->reserve((size_t)out.n_nodes * 32)); HIP_TRY(ctx, out.recs->reserve((size_t)T * 128));
         HIP_TRY(ctx, hipMemsetAsync(out.nodes->p, 0, 64, s));
         O.nodes = out.nodes->as<float4>(); O.recs = out.recs->as<float4>();
         hipLaunchKernelGGL(k_lbvh_emit_binary, grid, block, 0, s, A, inner.as<uint32_t>(), inner_rank.as<uint32_t>(), O);
-        hipLaunchKernelGGL(k_lbvh_emit_wide, grid, block, 0, s, A, inner.as<uint32_t>(), inner_rank.as<uint32_t>(), record.as<uint32_t>(), record_rank.as<uint32_t>(), O);
+        std::vector<uint32_t> per_level(deepest + 2, 0u);
+        per_level[0] = 1; // the root's record
+        HIP_TRY(ctx, front.reserve((size_t)T * 4)); HIP_TRY(ctx, level_count.reserve(per_level.size() * 4));
+        HIP_TRY(ctx, hipMemsetAsync(front.p, 0, 4, s)); // ... whose node is the root
+        HIP_TRY(ctx, hipMemcpyAsync(level_count.p, per_level.data(), per_level.size() * 4, hipMemcpyHostToDevice, s));
+        for (uint32_t level = 0; level < deepest; ++level)
+            hipLaunchKernelGGL(k_lbvh_wide_level, grid, block, 0, s, A, inner.as<uint32_t>(), inner_rank.as<uint32_t>(), front.as<uint32_t>(),
+                               level_count.as<uint32_t>(), level, O);
+        HIP_TRY(ctx, hipMemcpyAsync(per_level.data(), level_count.p, per_level.size() * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipStreamSynchronize(s));
+        for (uint32_t c : per_level) { R += c; out.wide_levels += c ? 1u : 0u; }
+        out.n_recs = R;
         out.root_word = node_base + 2; // the pair of the root's children: the root is the first kept inner node
         out.root4 = rec_base;          // ... and the first record
     } else { // a handful of triangles: the root is a leaf
@@ -688,6 +700,7 @@ static int build_bvh_gpu(rt_ctx *ctx, const rt_mesh &m, uint32_t node_base, uint
         HIP_TRY(ctx, out.nodes->reserve(64)); HIP_TRY(ctx, out.recs->reserve(1));
         out.root_word = 0x80000000u | ((n - 1) << 28) | tri_base;
         out.root4 = out.root_word;
+        deepest = 0;
         const float4 root[4] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(lo[0], hi[0], lo[1], hi[1]),
                                 make_float4(lo[2], hi[2], __builtin_bit_cast(float, out.root_word), 0.0f)};
         HIP_TRY(ctx, hipMemcpyAsync(out.nodes->p, root, sizeof root, hipMemcpyHostToDevice, s));
@@ -695,8 +708,6 @@ static int build_bvh_gpu(rt_ctx *ctx, const rt_mesh &m, uint32_t node_base, uint
     hipLaunchKernelGGL(k_lbvh_emit_tris, grid, block, 0, s, A, O);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->evk1, s));
-    uint32_t deepest = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(&deepest, maxd.p, 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));
     float ms = 0;
     HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->evk0, ctx->evk1));
@@ -715,7 +726,7 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc)
     // ---- validate: the kernels index with what is checked here ----
     const uint32_t nn = sc->n_nodes;
     std::vector<DNode> nodes(nn);
-    int max_mesh_depth = -1;
+    int max_mesh_depth = -1, max_wide_levels = 0; // levels of the deepest binary BVH, of the deepest four-wide one
     int ray_levels = 1;
     for (uint32_t i = 0; i < nn; ++i) {
         const rt_node &n = sc->nodes[i];
@@ -827,6 +838,7 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc)
         if (gpu_bvh) {
             const GpuBvh &g = built[mi];
             depth = g.depth;
+            max_wide_levels = std::max(max_wide_levels, (int)g.wide_levels);
             memcpy(roots[mi].bounds, g.bounds, sizeof g.bounds);
             roots[mi].data = g.root_word;
             root4[mi] = g.root4;
@@ -867,8 +879,9 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc)
         // the four-wide form: a record per inner node reached in steps of two levels from the root
         if (wide_gpu) { // (the frames' rays have a tree of their own, built above)
             root4[mi] = built[mi].root4;
-            depth = std::max(depth, built[mi].depth);
+            max_wide_levels = std::max(max_wide_levels, (int)built[mi].wide_levels);
         } else {
+            max_wide_levels = std::max(max_wide_levels, ((int)depth + 1) / 2); // a record per two levels
             const auto pooled = [&](uint32_t id) { return __builtin_bit_cast(uint32_t, bvh[(size_t)(nb + id) * 2 + 1].z); }; // data word, pool numbering
             const auto is_leaf = [&](uint32_t id) { return (m.bvh_nodes[id].data & 0x80000000u) != 0; };
             const float inf = std::numeric_limits<float>::infinity();
@@ -1099,8 +1112,8 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc)
     }
     DScene S{};
     // entries a lane's stack may hold: the binary walk pushes at most two nodes per level of the tree; the four-wide walk
-    // of the ray-list kernel goes down two levels per visit and pushes up to three nodes each time
-    S.stack_levels = max_mesh_depth < 0 ? 0 : std::max(max_mesh_depth + 2, 3 * ((max_mesh_depth + 1) / 2) + 2);
+    // of the ray-list kernel pushes up to three nodes per level of the wide tree
+    S.stack_levels = max_mesh_depth < 0 ? 0 : std::max(max_mesh_depth + 2, 3 * max_wide_levels + 2);
     // LDS holds the first levels of every lane's stack (26 KiB per 256 threads lets six
     // workgroups share a CU's 160 KiB); deeper entries spill to a global array sized
     // for the largest grid any entry point launches
