@@ -260,6 +260,20 @@ __global__ __launch_bounds__(kBlock, RT_PATHS_MIN_WAVES) void k_paths(DScene S, 
 // Zero bounces: tracePath's loop body never runs, so every sample is black; only the depth / id planes need the
 // first sample's camera ray.  A kernel of its own, because the same code as a never-taken branch of k_paths cost
 // the 1M-triangle frame 7 % (a second inlined copy of the scene walk in the register allocator's way).
+// the per-face shading records of a mesh (DMesh::face_rec) from its index and normal arrays
+__global__ __launch_bounds__(kBlock) void k_face_records(const uint32_t *__restrict__ fn, const float *__restrict__ vn,
+                                                         const uint32_t *__restrict__ fmtl, uint32_t n_faces, float4 *__restrict__ out)
+{
+    for (uint32_t f = blockIdx.x * kBlock + threadIdx.x; f < n_faces; f += gridDim.x * kBlock) {
+        const float *a = vn + (size_t)fn[f * 3] * 3, *b = vn + (size_t)fn[f * 3 + 1] * 3, *c = vn + (size_t)fn[f * 3 + 2] * 3;
+        float4 *rec = out + (size_t)f * 4;
+        rec[0] = make_float4(a[0], a[1], a[2], b[0]);
+        rec[1] = make_float4(b[1], b[2], c[0], c[1]);
+        rec[2] = make_float4(c[2], __uint_as_float(fmtl ? fmtl[f] : 0u), 0.0f, 0.0f);
+        rec[3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+}
+
 template <int LEVELS>
 __global__ __launch_bounds__(kBlock) void k_probe(DScene S, DFrame F, const float *__restrict__ halton,
                                                   const int32_t *__restrict__ active, uint64_t n_items, int k0, int nk,

@@ -69,6 +69,10 @@ struct DMesh {
     uint32_t n_nodes;
     uint32_t depth;
     const uint32_t *fmtl; // sub-material per face (rt_mesh::face_material), null unless the scene asks for per-face materials
+    // What shading a hit needs of its face, in one 64-byte record (one memory line instead of four: the face's normal
+    // indices and the three normals they name are 12-byte reads at unrelated addresses): four float4 per face =
+    // n0.xyz n1.x | n1.yz n2.xy | n2.z, sub-material, -, - | unused
+    const float4 *face_rec;
 };
 
 // One texture map (rt_texture with its pixels in device memory).

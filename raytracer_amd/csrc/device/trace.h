@@ -539,11 +539,11 @@ RT_DEV void finish_hit(const DScene &S, Ray ray, Hit &h, bool want_uvw)
         h.uvw = h.p * 0.5f + mk(1.0f, 1.0f, 1.0f);
     } else {
         const DMesh &M = S.meshes[nd.mesh];
-        const GU32 fn = (GU32)M.fn;
-        const GF32 vn = (GF32)M.vn;
-        const uint32_t n0 = fn[h.face * 3], n1 = fn[h.face * 3 + 1], n2 = fn[h.face * 3 + 2];
+        const GF4 rec = (GF4)M.face_rec + (size_t)h.face * 4;
+        const f4 a = rec[0], b = rec[1];
+        const float n2z = rec[2].x;
         const float w = 1.0f - h.u - h.v;
-        h.n = normalize((gld3(vn + n0 * 3) * w + gld3(vn + n1 * 3) * h.u) + gld3(vn + n2 * 3) * h.v);
+        h.n = normalize((mk(a.x, a.y, a.z) * w + mk(a.w, b.x, b.y) * h.u) + mk(b.z, b.w, n2z) * h.v);
         if (want_uvw) {
             const GU32 ft = (GU32)M.ft;
             const GF32 vt = (GF32)M.vt;
@@ -565,8 +565,8 @@ RT_DEV int hit_material(const DScene &S, int node, uint32_t face)
     const DNode &nd = S.nodes[node];
     int m = nd.material;
     if (S.face_materials && nd.prim == RT_PRIM_MESH) {
-        const GU32 fm = (GU32)S.meshes[nd.mesh].fmtl;
-        if (fm) m += (int)fm[face];
+        const DMesh &M = S.meshes[nd.mesh];
+        if (M.fmtl) m += (int)__float_as_uint(((GF4)M.face_rec)[(size_t)face * 4 + 2].y); // (beside the normals finish_hit reads)
     }
     return m;
 }

@@ -1,20 +1,22 @@
 // Wavefront form of the path tracer: the per-path arithmetic of path_step() (shade.h, src/main.cpp:160-268),
-// split so that rays, not paths, are the unit of SIMD work, with compacted ray lists between the stages.
+// split so that rays, not paths, are the unit of SIMD work, with compacted lists between the stages.
 //
-// All camera paths of a sampling round are in flight at once; a path keeps one slot (= its item index in the
-// sample buffer) for life, and its radiance accumulates in the sample buffer itself.  Per bounce the host runs
+// All camera paths of a sampling round are in flight at once.  A path has a slot (= its item index in the sample
+// buffer, where its radiance accumulates), but its state does not live there: it travels with the path from the list
+// of one bounce to the list of the next, so every list is dense - entry e of a list is entry e of the state arrays -
+// and a kernel that goes through a list reads whole memory lines of live paths, however few of the round's paths are
+// left.  Per bounce the host runs
 //
 //   k_rays<WfIO>   (rays.h) one launch over "extension rays of the live paths, then the shadow rays of the previous
 //                  bounce", with ray-level regeneration: a lane that finishes a ray takes the next one at once, so BVH
 //                  steps run with nearly full waves however unequal the walks are.  A closest-hit answer goes to the
-//                  path's slot; an unoccluded shadow ray adds the next-event contribution it carries to the path's
-//                  accumulator (one shadow ray per path and bounce, so no two lanes add to the same accumulator).
-//   k_wf_shade     one lane = one live path: shades the new hit (src/main.cpp:173-264), leaves the shadow ray with the
-//                  contribution it gates and, if the path goes on, the next extension ray in the path's slot, and
-//                  appends the slot to the shadow list / the next bounce's list.  A workgroup collects the entries of
-//                  2048 paths in LDS and reserves their place in a list with one atomic: a device-wide atomic per
-//                  wave (4 M of them on the first bounce of a 1080p x 64 spp round, all on one address) took longer
-//                  than the shading itself.
+//                  ray's list entry; an unoccluded shadow ray adds the next-event contribution it carries to its
+//                  path's accumulator (one shadow ray per path and bounce, so no two lanes add to the same one).
+//   k_wf_shade     one lane = one live path: shades the new hit (src/main.cpp:173-264) and appends the shadow ray with
+//                  the contribution it gates to the shadow list and, if the path goes on, the path with its next
+//                  extension ray to the next bounce's list.  A workgroup reserves the places of 256 paths' entries
+//                  with one atomic: a device-wide atomic per wave (4 M of them on the first bounce of a 1080p x 64 spp
+//                  round, all on one address) took longer than the shading itself.
 //
 // A path's random stream, draw order and every floating-point expression are those of path_step().  The rays go
 // through the four-wide walk of the ray-list kernel, which can report a hit one ulp away from the binary walk's when
@@ -28,18 +30,22 @@
 
 namespace rtd {
 
-// structure of arrays over the slots; every access is a 16-byte (or 8/4-byte) one
-struct WfState {
+// the paths of one extension list, entry by entry; every access is a 16-byte (or 8-byte) one
+struct WfPaths {
     float4 *ray_o;  // extension ray: origin xyz, w = probability of the bounce that produced it
     float4 *ray_d;  //                direction xyz, w = bits: bounce | lobe of that bounce << 16
-    float4 *thr;    // path throughput xyz
+    float4 *thr;    // path throughput xyz, w = bits: the path's slot
     uint2 *rng;     // PCG state (the increment follows from the sample index)
-    float4 *hit;    // answer to the extension ray: t, node, face | front << 31, u
-    float *hit_v;   //                              v
-    float4 *sh_o;   // shadow ray of the path's last vertex: origin xyz, w = t_max
-    float4 *sh_d;   //              direction xyz
-    float4 *sh_c;   //              next-event contribution the ray gates
-    float4 *acc;    // radiance accumulators = the sample buffer of the round
+};
+struct WfState {
+    WfPaths in;     // the list the kernel goes through (the camera paths: entry e is slot e, thr and rng not yet written)
+    WfPaths out;    // the next bounce's list, which k_wf_shade fills
+    float4 *hit;    // per entry of `in`, the answer to its extension ray: t, node, face | front << 31, u
+    float *hit_v;   //                                                     v
+    float4 *sh_o;   // per entry of the shadow list: origin xyz, w = t_max
+    float4 *sh_d;   //                               direction xyz
+    float4 *sh_c;   //                               next-event contribution the ray gates, w = bits: the path's slot
+    float4 *acc;    // per slot: radiance accumulators = the sample buffer of the round
 };
 
 // The lists of one bounce and their lengths, all in device memory: the host need not know the lengths to launch the
@@ -50,14 +56,12 @@ struct WfCounts {
     uint32_t pad[2];
 };
 
-// ray list of k_rays: the extension rays of the slots the queue names (slot e itself without a queue: the camera
-// rays), then the shadow rays of the slots the shadow queue names
+// ray list of k_rays: the extension rays of the list's paths, then the shadow rays of the shadow list
 struct WfIO {
     static constexpr bool kWide = true; // four-wide BVH walk: the depth / id planes come from k_planes, not from these rays
     static constexpr bool kDeferShadow = true;
     struct Pending { float4 c, a; };
     WfState P;
-    const uint32_t *queue, *sh_queue;
     const WfCounts *cnt;     // this bounce's list lengths
     uint32_t shadows_only;   // leave the extension rays alone: k_wf_finish takes them
     RT_DEV uint32_t setup(uint32_t, uint32_t &n_ext) const
@@ -65,38 +69,33 @@ struct WfIO {
         n_ext = shadows_only ? 0u : cnt->n_ext;
         return n_ext + cnt->n_shadow;
     }
-    RT_DEV void refetch(uint32_t slot, bool any_hit, float4 &o, float4 &d) const
-    {
-        if (any_hit) { o = P.sh_o[slot]; d = P.sh_d[slot]; }
-        else { o = P.ray_o[slot]; d = P.ray_d[slot]; }
-    }
-    // the lane keeps the slot: every later access goes straight to the path's arrays
-    RT_DEV bool fetch(uint32_t e, uint32_t n_ext, float4 &o, float4 &d, bool &any_hit, float &t_max, uint32_t &slot) const
+    // the lane keeps the ray's place in its own list
+    RT_DEV bool fetch(uint32_t e, uint32_t n_ext, float4 &o, float4 &d, bool &any_hit, float &t_max, uint32_t &at) const
     {
         any_hit = e >= n_ext;
-        slot = any_hit ? sh_queue[e - n_ext] : (queue ? queue[e] : e);
-        refetch(slot, any_hit, o, d);
+        at = any_hit ? e - n_ext : e;
+        if (any_hit) { o = P.sh_o[at]; d = P.sh_d[at]; }
+        else { o = P.in.ray_o[at]; d = P.in.ray_d[at]; }
         t_max = any_hit ? o.w : 0.0f;
         return true;
     }
     // an unoccluded shadow ray adds the contribution it gates to its path's accumulator
-    RT_DEV void begin_put_shadow(uint32_t slot, Pending &p) const { p.c = P.sh_c[slot]; p.a = P.acc[slot]; }
-    RT_DEV void end_put_shadow(uint32_t slot, const Pending &p) const
+    RT_DEV void begin_put_shadow(uint32_t at, Pending &p) const { p.c = P.sh_c[at]; p.a = P.acc[__float_as_uint(p.c.w)]; }
+    RT_DEV void end_put_shadow(uint32_t, const Pending &p) const
     {
-        P.acc[slot] = make_float4(p.a.x + p.c.x, p.a.y + p.c.y, p.a.z + p.c.z, p.a.w);
+        P.acc[__float_as_uint(p.c.w)] = make_float4(p.a.x + p.c.x, p.a.y + p.c.y, p.a.z + p.c.z, p.a.w);
     }
-    RT_DEV void put_closest(uint32_t slot, float t, int node, uint32_t face, int front, float u, float v) const
+    RT_DEV void put_closest(uint32_t at, float t, int node, uint32_t face, int front, float u, float v) const
     {
-        P.hit[slot] = make_float4(t, __uint_as_float((uint32_t)node), __uint_as_float(face | ((uint32_t)front << 31)), u);
-        P.hit_v[slot] = v;
+        P.hit[at] = make_float4(t, __uint_as_float((uint32_t)node), __uint_as_float(face | ((uint32_t)front << 31)), u);
+        P.hit_v[at] = v;
     }
-    RT_DEV void put_shadow(uint32_t slot, bool occluded) const
+    RT_DEV void put_shadow(uint32_t at, bool occluded) const
     {
         if (occluded) return;
-        const float4 c = P.sh_c[slot];
-        float4 a = P.acc[slot];
-        a.x = a.x + c.x; a.y = a.y + c.y; a.z = a.z + c.z;
-        P.acc[slot] = a;
+        Pending p;
+        begin_put_shadow(at, p);
+        end_put_shadow(at, p);
     }
 };
 
@@ -114,8 +113,8 @@ __global__ __launch_bounds__(kBlock) void k_wf_generate(DFrame F, const float *_
         float off[4];
         off[0] = rng_float(rng); off[1] = rng_float(rng); off[2] = rng_float(rng); off[3] = rng_float(rng);
         const Ray r = camera_ray(F, halton, pix % F.width, pix / F.width, k, off);
-        P.ray_o[item] = make_float4(r.p.x, r.p.y, r.p.z, 1.0f);
-        P.ray_d[item] = make_float4(r.d.x, r.d.y, r.d.z, __uint_as_float(0u));
+        P.in.ray_o[item] = make_float4(r.p.x, r.p.y, r.p.z, 1.0f);
+        P.in.ray_d[item] = make_float4(r.d.x, r.d.y, r.d.z, __uint_as_float(0u));
     }
 }
 
@@ -214,8 +213,7 @@ struct LaneIO {
 // fetches instead of two binary ones.  A pair whose path has ended takes the next one from the list.
 template <bool COUNT, int LEVELS>
 __global__ __launch_bounds__(kBlock) void k_wf_finish(DScene S, DFrame F, int k0, int nk, WfState P,
-                                                      const uint32_t *__restrict__ queue_in, const WfCounts *__restrict__ cnt,
-                                                      DCounters *ctr, unsigned long long *queue)
+                                                      const WfCounts *__restrict__ cnt, DCounters *ctr, unsigned long long *queue)
 {
     const uint32_t n_in = cnt->n_ext;
     extern __shared__ uint32_t lds[];
@@ -254,9 +252,11 @@ __global__ __launch_bounds__(kBlock) void k_wf_finish(DScene S, DFrame F, int k0
             const uint32_t rank = (uint32_t)__popcll(free_pairs & ((1ull << lane) - 1ull));
             if (b + want >= n_in) exhausted = true;
             if (keeper && !have_path && b + rank < n_in) {
-                slot = queue_in[b + rank];
-                const float4 ro = P.ray_o[slot], rd = P.ray_d[slot], t = P.thr[slot], a = P.acc[slot];
-                const uint2 rs = P.rng[slot];
+                const uint32_t at = (uint32_t)b + rank;
+                const float4 ro = P.in.ray_o[at], rd = P.in.ray_d[at], t = P.in.thr[at];
+                const uint2 rs = P.in.rng[at];
+                slot = __float_as_uint(t.w);
+                const float4 a = P.acc[slot];
                 const int k = k0 + (int)(slot % (uint32_t)nk);
                 const uint32_t bits = __float_as_uint(rd.w);
                 ray = Ray{mk(ro.x, ro.y, ro.z), mk(rd.x, rd.y, rd.z)};
@@ -318,11 +318,11 @@ __global__ __launch_bounds__(kBlock) void k_wf_finish(DScene S, DFrame F, int k0
     flush_counters<COUNT>(ctr, pt, tl, 0);
 }
 
-constexpr uint32_t kShadeRounds = 8;                      // paths per lane and list reservation
-constexpr uint32_t kShadeChunk = kShadeRounds * kBlock;   // paths per workgroup and list reservation
+constexpr uint32_t kShadeRounds = 8;                      // paths per lane and chunk
+constexpr uint32_t kShadeChunk = kShadeRounds * kBlock;   // paths a workgroup orders by what they hit
 constexpr uint32_t kShadeBins = 64;                       // nothing, lights, then the scene's nodes (the last bin takes the rest)
 
-// position of this lane's entry in the workgroup's LDS list: one LDS atomic per wave
+// position of this lane's entry among the workgroup's entries of this trip: one LDS atomic per wave
 RT_DEV uint32_t lds_append(uint32_t *count, bool want)
 {
     const uint64_t m = __ballot(want);
@@ -335,24 +335,23 @@ RT_DEV uint32_t lds_append(uint32_t *count, bool want)
     return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
 }
 
-// One bounce of every live path.  FIRST: the camera rays' hits - the list is implicit (slot e), the path state is
-// its initial value and need not have been written.  Adds to *next the paths that go on and the shadow rays.
+// One bounce of every live path.  FIRST: the camera rays' hits - entry e is slot e, the path state is its initial
+// value and need not have been written.  Appends to the lists of *next the paths that go on and the shadow rays.
 template <bool FIRST>
 __global__ __launch_bounds__(kBlock) void k_wf_shade(DScene S, DFrame F, const int32_t *__restrict__ active, int k0, int nk,
-                                                     WfState P, const uint32_t *__restrict__ queue_in,
-                                                     const WfCounts *__restrict__ cnt, uint32_t *__restrict__ queue_out,
-                                                     uint32_t *__restrict__ sh_queue_out, WfCounts *next, FramePlanes out)
+                                                     WfState P, const WfCounts *__restrict__ cnt, WfCounts *next, FramePlanes out)
 {
     const uint32_t n_in = cnt->n_ext;
-    uint32_t *const counts = &next->n_ext; // [0] paths that go on, [1] shadow rays
-    __shared__ uint32_t s_ext[kShadeChunk], s_sh[kShadeChunk];
+    // n_ext and n_shadow of the next bounce as one 64-bit word (low: paths that go on, high: shadow rays): a trip's
+    // places in both lists are reserved with one atomic
+    unsigned long long *const counts = (unsigned long long *)&next->n_ext;
     __shared__ uint32_t s_order[kShadeChunk]; // the chunk's paths, those that hit the same thing next to each other
     __shared__ uint32_t s_bin[kShadeBins];
-    __shared__ uint32_t s_n[2], s_base[2];
+    __shared__ uint32_t s_n[2][2], s_base[2]; // [trip parity][0: paths that go on, 1: shadow rays]
     const rt_light &light = S.lights[0];
     const uint32_t n_chunks = (n_in + kShadeChunk - 1) / kShadeChunk;
     for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
-    if (threadIdx.x < 2) s_n[threadIdx.x] = 0;
+    if (threadIdx.x < 4) (&s_n[0][0])[threadIdx.x] = 0;
     if (threadIdx.x < kShadeBins) s_bin[threadIdx.x] = 0;
     __syncthreads();
     // What a path does here depends on what it hit (nothing, a light, a sphere, a plane, a mesh; which material), and
@@ -361,17 +360,12 @@ __global__ __launch_bounds__(kBlock) void k_wf_shade(DScene S, DFrame F, const i
     // not all of them.  Every path's arithmetic is its own, so the order changes no result.
     const uint32_t chunk_first = chunk * kShadeChunk;
     const uint32_t chunk_n = n_in - chunk_first < kShadeChunk ? n_in - chunk_first : kShadeChunk;
-    uint32_t my_slot[kShadeRounds], my_key[kShadeRounds], my_rank[kShadeRounds];
-#pragma unroll
-    for (uint32_t r = 0; r < kShadeRounds; ++r) {
-        const uint32_t i = r * kBlock + threadIdx.x;
-        my_slot[r] = i < chunk_n ? (FIRST ? chunk_first + i : queue_in[chunk_first + i]) : 0u;
-    }
+    uint32_t my_key[kShadeRounds], my_rank[kShadeRounds];
 #pragma unroll
     for (uint32_t r = 0; r < kShadeRounds; ++r) {
         const uint32_t i = r * kBlock + threadIdx.x;
         if (i < chunk_n) {
-            const int node = (int)__float_as_uint(P.hit[my_slot[r]].y); // -1: nothing, below: a light
+            const int node = (int)__float_as_uint(P.hit[chunk_first + i].y); // -1: nothing, below: a light
             my_key[r] = node < 0 ? (node == -1 ? 1u : 0u) : ((uint32_t)node + 2u < kShadeBins ? (uint32_t)node + 2u : kShadeBins - 1u);
             my_rank[r] = atomicAdd(&s_bin[my_key[r]], 1u);
         }
@@ -388,37 +382,40 @@ __global__ __launch_bounds__(kBlock) void k_wf_shade(DScene S, DFrame F, const i
 #pragma unroll
     for (uint32_t r = 0; r < kShadeRounds; ++r) {
         const uint32_t i = r * kBlock + threadIdx.x;
-        if (i < chunk_n) s_order[s_bin[my_key[r]] + my_rank[r]] = my_slot[r];
+        if (i < chunk_n) s_order[s_bin[my_key[r]] + my_rank[r]] = chunk_first + i;
     }
     __syncthreads();
-    for (uint32_t r = 0; r < kShadeRounds; ++r) { // every lane takes every trip: the appends are wave-wide
+    for (uint32_t r = 0; r < kShadeRounds; ++r) { // every lane takes every trip: the appends are workgroup-wide
         const uint32_t i = r * kBlock + threadIdx.x;
         const bool live = i < chunk_n;
         bool want_ext = false, want_shadow = false;
         uint32_t slot = 0;
-        float4 new_o = make_float4(0, 0, 0, 0), new_d = new_o, s_o = new_o, s_d = new_o, s_c = new_o;
+        float4 new_o = make_float4(0, 0, 0, 0), new_d = new_o, new_t = new_o, s_o = new_o, s_d = new_o, s_c = new_o;
+        uint2 new_rng = make_uint2(0u, 0u);
         if (live) {
-            slot = s_order[i];
-            const float4 ro = P.ray_o[slot], rd = P.ray_d[slot];
+            const uint32_t at = s_order[i]; // the path's place in the list
+            const float4 ro = P.in.ray_o[at], rd = P.in.ray_d[at];
             const Ray ray{mk(ro.x, ro.y, ro.z), mk(rd.x, rd.y, rd.z)};
-            const uint32_t a = slot / (uint32_t)nk;
-            const int k = k0 + (int)(slot - a * (uint32_t)nk);
             V3 thr = mk(1.0f, 1.0f, 1.0f);
             float lastProb = 1.0f;
             int lastLobe = LOBE_NONE, bounce = 0;
+            slot = at;
             if (!FIRST) {
-                const float4 t = P.thr[slot];
+                const float4 t = P.in.thr[at];
                 thr = mk(t.x, t.y, t.z);
+                slot = __float_as_uint(t.w);
                 lastProb = ro.w;
                 const uint32_t bits = __float_as_uint(rd.w);
                 bounce = (int)(bits & 0xFFFFu); lastLobe = (int)(bits >> 16);
             }
-            const float4 hr = P.hit[slot];
+            const uint32_t a = slot / (uint32_t)nk;
+            const int k = k0 + (int)(slot - a * (uint32_t)nk);
+            const float4 hr = P.hit[at];
             Hit h;
             h.z = hr.x; h.node = (int)__float_as_uint(hr.y);
             const uint32_t ff = __float_as_uint(hr.z);
             h.face = ff & 0x7FFFFFFFu; h.front = (int)(ff >> 31);
-            h.u = hr.w; h.v = P.hit_v[slot];
+            h.u = hr.w; h.v = P.hit_v[at];
             const bool hit = h.node != -1;
             V3 add = mk(0.0f, 0.0f, 0.0f);
             bool adds = false;
@@ -441,7 +438,7 @@ __global__ __launch_bounds__(kBlock) void k_wf_shade(DScene S, DFrame F, const i
                 Rng rng;
                 if (FIRST) rng_set_sequence(rng, (uint64_t)k + 1, pixel_seed(F.seed, (uint64_t)active[a]));
                 else {
-                    const uint2 rs = P.rng[slot];
+                    const uint2 rs = P.in.rng[at];
                     rng.state = ((uint64_t)rs.y << 32) | rs.x;
                     rng.inc = (((uint64_t)k + 1) << 1u) | 1u;
                 }
@@ -469,7 +466,7 @@ __global__ __launch_bounds__(kBlock) void k_wf_shade(DScene S, DFrame F, const i
                 }
                 s_o = make_float4(so.x, so.y, so.z, ne.dist - F.bias);
                 s_d = make_float4(ne.dir.x, ne.dir.y, ne.dir.z, 0.0f);
-                s_c = make_float4(c.x, c.y, c.z, 0.0f);
+                s_c = make_float4(c.x, c.y, c.z, __uint_as_float(slot));
                 want_shadow = true;
                 // indirect bounce (main.cpp:253-264)
                 Sample in;
@@ -479,8 +476,8 @@ __global__ __launch_bounds__(kBlock) void k_wf_shade(DScene S, DFrame F, const i
                     thr = thr * (in.mult / in.prob);
                     new_o = make_float4(no.x, no.y, no.z, in.prob);
                     new_d = make_float4(in.dir.x, in.dir.y, in.dir.z, __uint_as_float((uint32_t)(bounce + 1) | ((uint32_t)in.lobe << 16)));
-                    P.thr[slot] = make_float4(thr.x, thr.y, thr.z, 0.0f);
-                    P.rng[slot] = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
+                    new_t = make_float4(thr.x, thr.y, thr.z, __uint_as_float(slot));
+                    new_rng = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
                     want_ext = true;
                 }
             }
@@ -491,17 +488,29 @@ __global__ __launch_bounds__(kBlock) void k_wf_shade(DScene S, DFrame F, const i
                 P.acc[slot] = acc;
             }
         }
-        const uint32_t qi = lds_append(&s_n[0], want_ext);
-        if (want_ext) { s_ext[qi] = slot; P.ray_o[slot] = new_o; P.ray_d[slot] = new_d; }
-        const uint32_t si = lds_append(&s_n[1], want_shadow);
-        if (want_shadow) { s_sh[si] = slot; P.sh_o[slot] = s_o; P.sh_d[slot] = s_d; P.sh_c[slot] = s_c; }
+        // the trip's places in the two lists
+        uint32_t *const n_trip = s_n[r & 1u];
+        const uint32_t qi = lds_append(&n_trip[0], want_ext);
+        const uint32_t si = lds_append(&n_trip[1], want_shadow);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t n_e = n_trip[0], n_s = n_trip[1];
+            unsigned long long b = 0;
+            if (n_e | n_s) b = atomicAdd(counts, (unsigned long long)n_e | ((unsigned long long)n_s << 32));
+            s_base[0] = (uint32_t)b; s_base[1] = (uint32_t)(b >> 32);
+            s_n[(r & 1u) ^ 1u][0] = 0; s_n[(r & 1u) ^ 1u][1] = 0; // the next trip's counters
+        }
+        __syncthreads();
+        if (want_ext) {
+            const uint32_t e = s_base[0] + qi;
+            P.out.ray_o[e] = new_o; P.out.ray_d[e] = new_d; P.out.thr[e] = new_t; P.out.rng[e] = new_rng;
+        }
+        if (want_shadow) {
+            const uint32_t j = s_base[1] + si;
+            P.sh_o[j] = s_o; P.sh_d[j] = s_d; P.sh_c[j] = s_c;
+        }
     }
-    __syncthreads();
-    if (threadIdx.x < 2 && s_n[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&counts[threadIdx.x], s_n[threadIdx.x]);
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < s_n[0]; i += kBlock) queue_out[s_base[0] + i] = s_ext[i];
-    for (uint32_t i = threadIdx.x; i < s_n[1]; i += kBlock) sh_queue_out[s_base[1] + i] = s_sh[i];
-    __syncthreads(); // the LDS lists are reused by the next chunk
+    __syncthreads(); // s_order and the counters are reused by the next chunk
     }
 }
 

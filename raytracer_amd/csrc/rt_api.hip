@@ -83,7 +83,7 @@ struct rt_ctx {
     int order_pixels = -1;    // RT_ORDER: 1 = always deal a frame's pixels expensive-first, 0 = never (tile order), default: for tile shards only
     DeviceBuf d_stack_ovf;
     // wavefront pipeline (device/wavefront.h): per-slot path state, the bounce lists, list counts, event pairs around the ray launches
-    DeviceBuf d_wf_state, d_wf_queue[2], d_wf_sh_queue, d_wf_counts;
+    DeviceBuf d_wf_state, d_wf_counts;
     // The list lengths a round went through, by what the round was (frame constants, items, samples, scene): a round
     // that comes again (the next frame of the same view) is launched from them without the host waiting for the device
     // after every bounce; the lengths the device then reports are compared with them afterwards.
@@ -301,23 +301,29 @@ static int render_wavefront(rt_ctx *ctx, const DFrame &F, const int32_t *act, ui
 {
     hipStream_t s = ctx->stream;
     const uint32_t items = (uint32_t)items64;
-    // per-slot arrays, 256-byte aligned sub-allocations of one buffer
-    const size_t sizes[9] = {16, 16, 16, 8, 16, 4, 16, 16, 16};
-    size_t offs[9], total = 0;
-    for (int i = 0; i < 9; ++i) { offs[i] = total; total += ((size_t)items * sizes[i] + 255) / 256 * 256; }
+    // per-entry arrays of the lists, 256-byte aligned sub-allocations of one buffer: the paths of the list a bounce goes
+    // through and of the list it fills (each at most `items` long), the answers to the extension rays, the shadow list
+    const size_t sizes[13] = {16, 16, 16, 8, 16, 16, 16, 8, 16, 4, 16, 16, 16};
+    size_t offs[13], total = 0;
+    for (int i = 0; i < 13; ++i) { offs[i] = total; total += ((size_t)items * sizes[i] + 255) / 256 * 256; }
     HIP_TRY(ctx, ctx->d_wf_state.reserve(total));
-    for (auto &q : ctx->d_wf_queue) HIP_TRY(ctx, q.reserve((size_t)items * 4));
-    HIP_TRY(ctx, ctx->d_wf_sh_queue.reserve((size_t)items * 4));
     const int n_entries = F.max_bounces + 4;
     HIP_TRY(ctx, ctx->d_wf_counts.reserve((size_t)n_entries * sizeof(WfCounts)));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_wf_counts.p, 0, (size_t)n_entries * sizeof(WfCounts), s));
     WfCounts *const cnt = ctx->d_wf_counts.as<WfCounts>();
     char *base = ctx->d_wf_state.as<char>();
+    WfPaths lists[2];
+    for (int i = 0; i < 2; ++i) {
+        lists[i].ray_o = (float4 *)(base + offs[4 * i]); lists[i].ray_d = (float4 *)(base + offs[4 * i + 1]);
+        lists[i].thr = (float4 *)(base + offs[4 * i + 2]); lists[i].rng = (uint2 *)(base + offs[4 * i + 3]);
+    }
     WfState P;
-    P.ray_o = (float4 *)(base + offs[0]); P.ray_d = (float4 *)(base + offs[1]); P.thr = (float4 *)(base + offs[2]);
-    P.rng = (uint2 *)(base + offs[3]); P.hit = (float4 *)(base + offs[4]); P.hit_v = (float *)(base + offs[5]);
-    P.sh_o = (float4 *)(base + offs[6]); P.sh_d = (float4 *)(base + offs[7]); P.sh_c = (float4 *)(base + offs[8]);
+    P.in = lists[0]; P.out = lists[1];
+    P.hit = (float4 *)(base + offs[8]); P.hit_v = (float *)(base + offs[9]);
+    P.sh_o = (float4 *)(base + offs[10]); P.sh_d = (float4 *)(base + offs[11]); P.sh_c = (float4 *)(base + offs[12]);
     P.acc = ctx->d_sbuf.as<float4>();
+    // bounce b goes through lists[b & 1] and fills the other
+    const auto state_of = [&](int b) { WfState q = P; q.in = lists[b & 1]; q.out = lists[(b & 1) ^ 1]; return q; };
 
     if (k0 == 0 && (planes.z || planes.object_id)) { // depth / id planes: the first samples' camera rays through the reference's walk
         const uint32_t n_px = items / (uint32_t)nk;
@@ -343,12 +349,11 @@ static int render_wavefront(rt_ctx *ctx, const DFrame &F, const int32_t *act, ui
     DScene a_scene = ctx->scene;
     DCounters *a_ctr = ctx->d_counters.as<DCounters>();
     unsigned long long *a_queue = ctx->d_queue.as<unsigned long long>();
-    uint32_t *const sh_queue = ctx->d_wf_sh_queue.as<uint32_t>();
     int launch = 0;
     // one ray launch over the lists of bounce b (n_rays: what the host knows of their total length, for the grid)
-    const auto launch_rays = [&](int b, const uint32_t *queue_in, uint64_t n_rays, bool shadows_only) -> int {
+    const auto launch_rays = [&](int b, uint64_t n_rays, bool shadows_only) -> int {
         const dim3 grid((unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_rays + kBlock - 1) / kBlock, (uint64_t)ctx->n_cu * per_cu)));
-        WfIO a_io{P, queue_in, sh_queue, cnt + b, shadows_only ? 1u : 0u};
+        WfIO a_io{state_of(b), cnt + b, shadows_only ? 1u : 0u};
         uint32_t a_n = (uint32_t)b, a_chunk = 0; // the kernel takes the list's length from cnt[b] and sizes the portions itself (the bounce number only serves diagnostic builds)
         void *targs[] = {&a_scene, &a_io, &a_n, &a_ctr, &a_queue, &a_chunk};
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue.p, 0, kQueueBytes, s));
@@ -381,12 +386,10 @@ static int render_wavefront(rt_ctx *ctx, const DFrame &F, const int32_t *act, ui
     }
     WfCounts h = seen[0]; // the host's idea of cnt[b]
     bool finishing = false;
-    int cur = 0;
-    const uint32_t *queue_in = nullptr; // the camera rays: slot e
     for (int b = 0;; ++b) {
         const uint64_t n_live = h.n_ext;
         if (finishing) { // the shadow rays of the last shaded bounce, then the remaining paths to their ends in one launch
-            if (h.n_shadow > 0) if (int rc = launch_rays(b, queue_in, h.n_shadow, true)) return rc;
+            if (h.n_shadow > 0) if (int rc = launch_rays(b, h.n_shadow, true)) return rc;
             const void *ff = ctx->counting ? (ctx->ray_levels <= 1 ? (const void *)k_wf_finish<true, 1> : ctx->ray_levels == 2 ? (const void *)k_wf_finish<true, 2> : (const void *)k_wf_finish<true, 5>)
                                            : (scene_levels(ctx) == 0 ? (const void *)k_wf_finish<false, 0> : ctx->ray_levels <= 1 ? (const void *)k_wf_finish<false, 1> : ctx->ray_levels == 2 ? (const void *)k_wf_finish<false, 2> : (const void *)k_wf_finish<false, 5>);
             // a pair of lanes per path
@@ -395,21 +398,19 @@ static int render_wavefront(rt_ctx *ctx, const DFrame &F, const int32_t *act, ui
             int f_k0 = k0, f_nk = nk;
             const WfCounts *f_cnt = cnt + b;
             HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue.p, 0, kQueueBytes, s));
-            void *fargs[] = {&a_scene, &f_frame, &f_k0, &f_nk, &P, &queue_in, &f_cnt, &a_ctr, &a_queue};
+            WfState f_state = state_of(b);
+            void *fargs[] = {&a_scene, &f_frame, &f_k0, &f_nk, &f_state, &f_cnt, &a_ctr, &a_queue};
             HIP_TRY(ctx, hipLaunchKernel(ff, grid, dim3(kBlock), fargs, lds, s));
             break;
         }
         if (n_live + h.n_shadow == 0) break;
-        if (int rc = launch_rays(b, queue_in, n_live + h.n_shadow, false)) return rc;
+        if (int rc = launch_rays(b, n_live + h.n_shadow, false)) return rc;
         if (n_live == 0) break; // those were the last shadow rays
         {
             const dim3 grid((unsigned)std::min<uint64_t>((n_live + kShadeChunk - 1) / kShadeChunk, (uint64_t)ctx->n_cu * 16));
-            uint32_t *queue_out = ctx->d_wf_queue[cur].as<uint32_t>();
-            if (b == 0) hipLaunchKernelGGL(k_wf_shade<true>, grid, dim3(kBlock), 0, s, a_scene, F, act, k0, nk, P, queue_in, cnt + b, queue_out, sh_queue, cnt + b + 1, planes);
-            else hipLaunchKernelGGL(k_wf_shade<false>, grid, dim3(kBlock), 0, s, a_scene, F, act, k0, nk, P, queue_in, cnt + b, queue_out, sh_queue, cnt + b + 1, planes);
+            if (b == 0) hipLaunchKernelGGL(k_wf_shade<true>, grid, dim3(kBlock), 0, s, a_scene, F, act, k0, nk, state_of(b), cnt + b, cnt + b + 1, planes);
+            else hipLaunchKernelGGL(k_wf_shade<false>, grid, dim3(kBlock), 0, s, a_scene, F, act, k0, nk, state_of(b), cnt + b, cnt + b + 1, planes);
             HIP_TRY(ctx, hipGetLastError());
-            queue_in = queue_out;
-            cur ^= 1;
         }
         if (replay && (size_t)b + 1 < known->counts.size()) h = known->counts[b + 1];
         else if (replay) h = WfCounts{0u, 0u, {0u, 0u}}; // (the profile ends here; the check below tells if the device's lists do too)
@@ -941,7 +942,15 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc)
             HIP_TRY(ctx, upload(m.face_material, (size_t)m.nf * 4, (const void **)&d.fmtl));
             any_face_materials = true;
         }
+        auto rec = std::make_unique<DeviceBuf>();
+        HIP_TRY(ctx, rec->reserve(std::max<size_t>(1, (size_t)m.nf * 64)));
+        if (m.nf) hipLaunchKernelGGL(k_face_records, dim3((unsigned)std::min<size_t>(((size_t)m.nf + kBlock - 1) / kBlock, (size_t)ctx->n_cu * 16)), dim3(kBlock), 0,
+                                     ctx->stream, d.fn, d.vn, d.fmtl, m.nf, rec->as<float4>());
+        HIP_TRY(ctx, hipGetLastError());
+        d.face_rec = rec->as<float4>();
+        bufs.push_back(std::move(rec));
     }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     const float4 *d_bvh_pool = nullptr, *d_tri_pool = nullptr, *d_bvh4_pool = nullptr, *d_tri4_pool = nullptr;
     if (sc->n_meshes && gpu_bvh) { // the meshes' parts, each built in pool numbering, side by side in the three pools
         auto pool = [&](size_t bytes, const void **dst) -> hipError_t {
