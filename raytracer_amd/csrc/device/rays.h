@@ -165,7 +165,7 @@ template <bool COUNT, int LEVELS, class IO> struct RayWalker {
     RT_DEV void finish_closest(const DScene &S, const IO &io)
     {
         for (int l = 0; l < S.n_lights; ++l) {
-            const rt_light &L = S.lights[l];
+            const rt_light L = load_uniform(&S.lights[l]);
             if (L.type != RT_LIGHT_POINT) continue;
             Ray r;
             r.p = wray.p - ld3(L.position);
@@ -216,7 +216,7 @@ template <bool COUNT, int LEVELS, class IO> struct RayWalker {
         int cursor = 0;
         while (cursor < S.n_tlas) { // every lane of the wave stays in this loop to its end: the votes need them all
             const int c = __builtin_amdgcn_readfirstlane(cursor);
-            const TlasNode &tn = S.tlas[c];
+            const TlasNode tn = load_uniform(&S.tlas[c]);
             const int skip = tn.skip, obj = tn.object;
             const bool here = mine && active && !in_bvh && !stopped;
             const bool behind = c < node_i; // the lane has been past this record already
@@ -238,7 +238,7 @@ template <bool COUNT, int LEVELS, class IO> struct RayWalker {
                     if (ok && (t < best_t || (t == best_t && obj < best_node))) { best_t = t; best_node = obj; best_front = front; best_face = 0; best_u = 0; best_v = 0; }
                 }
             } else if (prim == RT_PRIM_MESH) {
-                const TNode &tm = S.tnodes[obj];
+                const TNode tm = load_uniform(&S.tnodes[obj]);
                 const V3 iv = mk(1.0f / l.d.x, 1.0f / l.d.y, 1.0f / l.d.z);
                 const bool ex = needs_exact_slabs(l.p, iv);
                 const float lim = any_hit ? t_max : FLT_MAX;
@@ -295,7 +295,7 @@ template <bool COUNT, int LEVELS, class IO> struct RayWalker {
         bool noted = false;   // a mesh entry waits for the end of the pass
         bool stopped = false; // ... and the lane has met a second mesh
         for (int n = 0; n < S.n_nodes; ++n) {
-            const TNode &nd = S.tnodes[n];
+            const TNode nd = load_uniform(&S.tnodes[n]);
             const uint32_t meta = nd.meta;
             const int prim = (int)(meta & 0xFFu), d = (int)((meta >> 8) & 0xFFu);
             const bool has_children = (meta >> 16) != 0;

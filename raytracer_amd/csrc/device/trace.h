@@ -175,6 +175,22 @@ constexpr uint32_t kLeafBit = 0x80000000u;
 // two counters); they are device-global by construction, and saying so gives global loads.
 #define RT_GLOBAL_AS __attribute__((address_space(1)))
 typedef float f4 __attribute__((ext_vector_type(4))); // native vector: loadable from any address space
+// A record of a scene table every lane of the wave reads at the same index (the index must be wave-uniform: a loop
+// counter, a readfirstlane), through the scalar cache into scalar registers.  Left to itself the compiler fetches
+// such a record with vector loads, field by field as the code comes to them - a handful of dependent round trips
+// through the vector memory path for every record, with the wave's lanes all holding the same values.  The tables are
+// never written while a kernel runs.
+#define RT_CONST_AS __attribute__((address_space(4)))
+template <class T> RT_DEV T load_uniform(const T *p)
+{
+    static_assert(sizeof(T) % 4 == 0, "whole dwords");
+    T out;
+    const RT_CONST_AS uint32_t *src = (const RT_CONST_AS uint32_t *)(const void *)p;
+    uint32_t *dst = (uint32_t *)(void *)&out;
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 4; ++i) dst[i] = src[i];
+    return out;
+}
 typedef const RT_GLOBAL_AS f4 *GF4;
 typedef const RT_GLOBAL_AS float *GF32;
 typedef const RT_GLOBAL_AS uint32_t *GU32;
