@@ -155,7 +155,7 @@ __global__ __launch_bounds__(kBlock, RT_PHOTON_MIN_WAVES) void k_photon_paths(DS
     PathTally pt;
     Tally<false> tl;
     uint32_t paths = 0;
-    const rt_light &light = S.lights[0];
+    const rt_light light = load_uniform(&S.lights[0]);
     const bool caustics_map = which == RT_MAP_CAUSTICS;
     const bool direct_only = !caustics_map && (P.flags & (RT_PM_DIRECT | RT_PM_MONTE_CARLO));
     const uint64_t seed = P.seed ^ (caustics_map ? kSeedCausticsMap : kSeedGlobalMap);

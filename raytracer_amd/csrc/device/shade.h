@@ -245,7 +245,7 @@ RT_DEV bool path_step(const DScene &S, const DFrame &F, PathState &ps, LaneStack
 {
     if (ps.bounce >= F.max_bounces) return false;
     tl.step(6);
-    const rt_light &light = S.lights[0];
+    const rt_light light = load_uniform(&S.lights[0]);
     const float bias = F.bias;
     const Ray ray = ps.ray;
     Hit h;

@@ -457,18 +457,18 @@ RT_DEV bool trace_closest(const DScene &S, Ray ray, LaneStack st, Hit &h, Tally<
         // lane's closest hit so far.  Objects come up in the hierarchy's order, not the list's, so of two hits at
         // exactly the same distance the one that is first in the list is kept explicitly (the reference keeps the first
         // it meets, and it meets them in list order).
-        const Ray r0 = to_node(S.nodes[0], ray); // the root node's space
+        const Ray r0 = to_node(load_uniform(&S.nodes[0]), ray); // the root node's space
         int cursor = 0;
         while (cursor < S.n_tlas) {
-            const TlasNode &tn = S.tlas[__builtin_amdgcn_readfirstlane(cursor)];
+            const TlasNode tn = load_uniform(&S.tlas[__builtin_amdgcn_readfirstlane(cursor)]);
             const bool reach = reaches_box(tn.box, ray.p, winv, h.z);
             if (!__any(reach)) { cursor = tn.skip; continue; }
             ++cursor;
             const int i = tn.object;
             if (i < 0 || !reach) continue;
-            const DNode &nd = S.nodes[i];
+            const DNode nd = load_uniform(&S.nodes[i]);
             Ray lr = r0;
-            for (int k = 1; k <= nd.depth; ++k) lr = to_node(S.nodes[nd.chain[k]], lr);
+            for (int k = 1; k <= nd.depth; ++k) lr = to_node(load_uniform(&S.nodes[nd.chain[k]]), lr);
             const int prim = nd.prim;
             float t = 0; int front = 1; bool ok = false;
             uint32_t face = 0; float u = 0, v = 0;
@@ -476,14 +476,14 @@ RT_DEV bool trace_closest(const DScene &S, Ray ray, LaneStack st, Hit &h, Tally<
             else if (prim == RT_PRIM_PLANE) ok = plane_t(lr, t, front);
             else {
                 float det = 0;
-                ok = mesh_closest<COUNT>(S.meshes[nd.mesh], lr, st, t, face, u, v, det, tl);
+                ok = mesh_closest<COUNT>(load_uniform(&S.meshes[nd.mesh]), lr, st, t, face, u, v, det, tl);
                 front = det > 0.0f;
             }
             if (ok && (t < h.z || (t == h.z && i < h.node))) { h.z = t; h.node = i; h.front = front; h.face = face; h.u = u; h.v = v; }
         }
     }
     for (int i = 0; i < n; ++i) {
-        const DNode &nd = S.nodes[i];
+        const DNode nd = load_uniform(&S.nodes[i]);
         const int d = nd.depth;
         // one vote per node: does any ray of the wave reach the object's box?
         const bool reach = CULL && reaches_box(nd.wbox, ray.p, winv, h.z);
@@ -503,7 +503,7 @@ RT_DEV bool trace_closest(const DScene &S, Ray ray, LaneStack st, Hit &h, Tally<
         else if (prim == RT_PRIM_PLANE) ok = plane_t(lr, t, front);
         else {
             float det = 0;
-            ok = mesh_closest<COUNT>(S.meshes[nd.mesh], lr, st, t, face, u, v, det, tl);
+            ok = mesh_closest<COUNT>(load_uniform(&S.meshes[nd.mesh]), lr, st, t, face, u, v, det, tl);
             front = det > 0.0f;
         }
         if (ok && t < h.z) { h.z = t; h.node = i; h.front = front; h.face = face; h.u = u; h.v = v; }
@@ -511,7 +511,7 @@ RT_DEV bool trace_closest(const DScene &S, Ray ray, LaneStack st, Hit &h, Tally<
     bool hit = h.node >= 0;
     // spherical lights, front side only (src/lights.h:129-156 via the default hitSide of scene.h:273)
     for (int l = 0; l < S.n_lights; ++l) {
-        const rt_light &L = S.lights[l];
+        const rt_light L = load_uniform(&S.lights[l]);
         if (L.type != RT_LIGHT_POINT) continue;
         Ray r;
         r.p = (ray.p - ld3(L.position)) / L.size;
@@ -600,29 +600,29 @@ RT_DEV bool trace_shadow(const DScene &S, Ray ray, float t_max, LaneStack st, Ta
     const int n = (CULL && S.n_tlas > 0) ? 0 : S.n_nodes;
     bool occluded = false;
     if (CULL && S.n_tlas > 0) { // as in trace_closest; a lane that has its occluder stays in the walk and votes "no"
-        const Ray r0 = to_node(S.nodes[0], ray);
+        const Ray r0 = to_node(load_uniform(&S.nodes[0]), ray);
         int cursor = 0;
         while (cursor < S.n_tlas) {
-            const TlasNode &tn = S.tlas[__builtin_amdgcn_readfirstlane(cursor)];
+            const TlasNode tn = load_uniform(&S.tlas[__builtin_amdgcn_readfirstlane(cursor)]);
             const bool reach = !occluded && reaches_box(tn.box, ray.p, winv, t_max);
             if (!__any(reach)) { cursor = tn.skip; continue; }
             ++cursor;
             const int i = tn.object;
             if (i < 0) continue;
             if (reach) {
-                const DNode &nd = S.nodes[i];
+                const DNode nd = load_uniform(&S.nodes[i]);
                 Ray lr = r0;
-                for (int k = 1; k <= nd.depth; ++k) lr = to_node(S.nodes[nd.chain[k]], lr);
+                for (int k = 1; k <= nd.depth; ++k) lr = to_node(load_uniform(&S.nodes[nd.chain[k]]), lr);
                 const int prim = nd.prim;
                 if (prim == RT_PRIM_SPHERE) occluded = sphere_shadow(lr, t_max);
                 else if (prim == RT_PRIM_PLANE) occluded = plane_shadow(lr, t_max);
-                else occluded = mesh_shadow<COUNT>(S.meshes[nd.mesh], lr, t_max, st, tl);
+                else occluded = mesh_shadow<COUNT>(load_uniform(&S.meshes[nd.mesh]), lr, t_max, st, tl);
             }
             if (__all(occluded)) break;
         }
     }
     for (int i = 0; i < n; ++i) {
-        const DNode &nd = S.nodes[i];
+        const DNode nd = load_uniform(&S.nodes[i]);
         const int d = nd.depth;
         const bool reach = CULL && !occluded && reaches_box(nd.wbox, ray.p, winv, t_max);
         const bool skip = CULL && (nd.prim == RT_PRIM_NONE || !__any(reach));
@@ -639,14 +639,14 @@ RT_DEV bool trace_shadow(const DScene &S, Ray ray, float t_max, LaneStack st, Ta
             if (!occluded) {
                 if (prim == RT_PRIM_SPHERE) occluded = sphere_shadow(lr, t_max);
                 else if (prim == RT_PRIM_PLANE) occluded = plane_shadow(lr, t_max);
-                else occluded = mesh_shadow<COUNT>(S.meshes[nd.mesh], lr, t_max, st, tl);
+                else occluded = mesh_shadow<COUNT>(load_uniform(&S.meshes[nd.mesh]), lr, t_max, st, tl);
             }
             if (__all(occluded)) break;
         } else {
             bool occ;
             if (prim == RT_PRIM_SPHERE) occ = sphere_shadow(lr, t_max);
             else if (prim == RT_PRIM_PLANE) occ = plane_shadow(lr, t_max);
-            else occ = mesh_shadow<COUNT>(S.meshes[nd.mesh], lr, t_max, st, tl);
+            else occ = mesh_shadow<COUNT>(load_uniform(&S.meshes[nd.mesh]), lr, t_max, st, tl);
             if (occ) return true;
         }
     }

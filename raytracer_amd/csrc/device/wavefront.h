@@ -218,7 +218,7 @@ __global__ __launch_bounds__(kBlock) void k_wf_finish(DScene S, DFrame F, int k0
     const uint32_t n_in = cnt->n_ext;
     extern __shared__ uint32_t lds[];
     const LaneStack st = lane_stack(lds, S);
-    const rt_light &light = S.lights[0];
+    const rt_light light = load_uniform(&S.lights[0]);
     const uint32_t lane = threadIdx.x & 63u;
     const bool keeper = (lane & 1u) == 0; // even lane: the path and its extension rays; odd lane: its shadow rays
     const int even = (int)(lane & ~1u), odd = (int)(lane | 1u);
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(kBlock) void k_wf_shade(DScene S, DFrame F, const i
     __shared__ uint32_t s_order[kShadeChunk]; // the chunk's paths, those that hit the same thing next to each other
     __shared__ uint32_t s_bin[kShadeBins];
     __shared__ uint32_t s_n[2][2], s_base[2]; // [trip parity][0: paths that go on, 1: shadow rays]
-    const rt_light &light = S.lights[0];
+    const rt_light light = load_uniform(&S.lights[0]);
     const uint32_t n_chunks = (n_in + kShadeChunk - 1) / kShadeChunk;
     for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
     if (threadIdx.x < 4) (&s_n[0][0])[threadIdx.x] = 0;

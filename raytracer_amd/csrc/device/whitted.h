@@ -223,7 +223,7 @@ __global__ __launch_bounds__(kBlock, RT_WHITTED_MIN_WAVES) void k_whitted(DScene
         } else if (state == W_SHADOW) {
             ++pt.shadow;
             const bool occluded = trace_shadow<COUNT, LEVELS, kWhittedCull>(S, ray, tmax, st, tl);
-            const rt_light &L = S.lights[l];
+            const rt_light L = load_uniform(&S.lights[l]);
             const rt_material &m = S.materials[mtl];
             if (L.type == RT_LIGHT_DIRECT) {
                 whitted_light_term(cur, m, ld3(L.intensity) * (occluded ? 0.0f : 1.0f), -ld3(L.direction));
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(kBlock, RT_WHITTED_MIN_WAVES) void k_whitted(DScene
             int child = -1; // pending combination of the child ray to spawn, -1 = none
             if (stage == STG_LIGHT) {
                 if (l >= S.n_lights || (pm & RT_PM_DIRECT)) { stage = STG_AFTER; continue; } // no light loop when the map holds the direct light
-                const rt_light &L = S.lights[l];
+                const rt_light L = load_uniform(&S.lights[l]);
                 if (L.type == RT_LIGHT_AMBIENT) { // p12 lights.h:33, materials.cpp:28-31
                     cur.final = cur.final + cur.kd * ld3(L.intensity);
                     ++l;
