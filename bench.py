@@ -94,20 +94,25 @@ def build_scene(name):
     return hs, w, h, spp, len(mesh["f"]), abi.RT_MODE_PATH, 50, None
 
 
-def algorithmic_flops(desc, c, mode=abi.RT_MODE_PATH):
-    """Flops one frame needs by the reference's own algorithm, from the kernels' ray / visit counters."""
+def algorithmic_flops(desc, c, mode=abi.RT_MODE_PATH, object_tests=None):
+    """Flops one frame needs by the reference's own algorithm, from the kernels' ray / visit counters.
+    object_tests: price the scene walk on the object tests the kernels made (a diagnostic build counts them)
+    instead of the reference's "every ray against every node"."""
     prims = [desc.nodes[i].prim for i in range(desc.n_nodes)]
     n_nodes, n_sph, n_pl = desc.n_nodes, prims.count(abi.RT_PRIM_SPHERE), prims.count(abi.RT_PRIM_PLANE)
     per_closest = F_NODE * n_nodes + F_SPH * n_sph + F_PLANE * n_pl + F_LIGHT * desc.n_lights
     per_shadow = F_NODE * n_nodes + F_SPH_SH * n_sph + F_PLANE * n_pl
+    walk = c.closest_rays * per_closest + c.shadow_rays * per_shadow
+    if object_tests is not None:  # an object test = the ray into the object's space + the average primitive test
+        per_object = F_NODE + (F_SPH * n_sph + F_PLANE * n_pl) / max(1, n_sph + n_pl)
+        walk = object_tests * per_object + c.closest_rays * F_LIGHT * desc.n_lights
     # path tracer: every shaded surface vertex sends exactly one shadow ray; Whitted-style shader: a vertex is a
     # closest hit on a surface (about as many as closest rays) and its shading is ~120 flops + ~60 per fan ray
     if mode == abi.RT_MODE_WHITTED:
-        return (c.closest_rays * (per_closest + 2 * F_BACK + 120) + c.shadow_rays * (per_shadow + 60)
+        return (walk + c.closest_rays * (2 * F_BACK + 120) + c.shadow_rays * 60
                 + F_BOX * c.box_tests + F_TRI * c.tri_tests + 20 * c.photon_visits)
     vertices = c.shadow_rays
-    return (c.closest_rays * per_closest + c.shadow_rays * per_shadow + F_BOX * c.box_tests + F_TRI * c.tri_tests
-            + vertices * (2 * F_BACK + F_SHADE))
+    return walk + F_BOX * c.box_tests + F_TRI * c.tri_tests + vertices * (2 * F_BACK + F_SHADE)
 
 
 def algorithmic_bytes(c, pixels):
@@ -115,16 +120,25 @@ def algorithmic_bytes(c, pixels):
     return B_BOX * c.box_tests + B_TRI * c.tri_tests + B_HIT * c.shadow_rays + B_PIXEL * pixels
 
 
-def measured_traffic(workload, kernel):
-    """Memory-side bytes per launch of the dominant kernel from the newest committed counter summary
-    (rocprofv3 --pmc passes of this same command, see tests/prof_round.sh); None if there is none."""
+def measured_counters(workload, kernel):
+    """The newest committed counter summary of the dominant kernel on this workload (rocprofv3 --pmc passes of this
+    same command, see tests/prof_round.sh and tests/prof_sq.sh) -> (memory-side bytes per launch, issue figures,
+    file name); (None, None, None) if there is none."""
     import glob
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_{kernel}.json")), reverse=True):
         d = json.load(open(f))
-        if d.get("workload") == workload:
-            m = d["memory_side"]
-            return (m["read_bytes"] + m["write_bytes"]) / d.get("launches_profiled", 1), os.path.basename(f)
-    return None, None
+        if d.get("workload") != workload:
+            continue
+        m = d["memory_side"]
+        sq = d.get("sq", {})
+        issue = None
+        if sq.get("SQ_ACTIVE_INST_VALU") and sq.get("SQ_WAVE_CYCLES"):
+            issue = {"lanes_per_valu_instruction": sq["SQ_THREAD_CYCLES_VALU"] / sq["SQ_ACTIVE_INST_VALU"],
+                     "waves_waiting": sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"],
+                     "valu_instructions_per_launch": sq["SQ_INSTS_VALU"] / d.get("launches_profiled", 1),
+                     "salu_instructions_per_launch": sq["SQ_INSTS_SALU"] / d.get("launches_profiled", 1)}
+        return (m["read_bytes"] + m["write_bytes"]) / d.get("launches_profiled", 1), issue, os.path.basename(f)
+    return None, None, None
 
 
 def cpu_baseline(hs, w, h, prm_gpu, pp, budget_s=12.0):
@@ -333,15 +347,57 @@ def main():
         avg_launch_s = kernel_ms / max(1, launches) / 1e3
         tflops = flops_launch / avg_launch_s / 1e12
         gbps = bytes_launch / avg_launch_s / 1e9
-        traffic, traffic_src = measured_traffic(args.workload, kernel) if world == 1 and headline else (None, None)
+        traffic, issue, traffic_src = measured_counters(args.workload, kernel) if world == 1 else (None, None, None)
         valu = {"achieved": tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": tflops / PEAK_FP32_TFLOPS,
                 "algorithmic_gflop_per_launch": flops_launch / 1e9}
         hbm = {"achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
                "algorithmic_gbyte_per_launch": bytes_launch / 1e9}
-        # the BVH walk and the photon gather are dependent fetches: memory bounds them; a scene of spheres and planes
-        # (every ray tests every node, the node list sits in the scalar cache) is bounded by FP32 VALU work
-        mem_bound = ntri > 0 or pp is not None
-        first, second, second_key = (hbm, valu, "valu_fp32") if mem_bound else (valu, hbm, "hbm")
+        # The contract's figure is algorithmic bytes (or flops) over time; `bound` says what the kernel is in fact held by.
+        if ntri > 0:
+            first, second, second_key, bound = hbm, valu, "valu_fp32", "valu_issue"
+            note = ("k_rays, rank 0's launches. `achieved` is the contract's figure: the bytes of the REFERENCE's walk (28 B per box "
+                    "test and 52 B per triangle test of its binary BVH, counted by the counting variant of the kernel, which walks "
+                    "that tree) over the launch time of the timed kernel - which walks a four-wide tree built on the GPU and needs "
+                    "fewer bytes for the same rays, so the figure can pass the HBM peak and is no bound on this kernel. `traffic` is "
+                    "what the memory side saw per launch (counter passes of this command); the BVH and triangle pools stay in the "
+                    "256 MiB Infinity Cache, so even that is fabric traffic, not DRAM reads. The kernel is held by instruction issue: "
+                    "waves run partly filled (`issue.lanes_per_valu_instruction` of 64) and wait for dependent node fetches "
+                    "(`issue.waves_waiting`).")
+        elif pp is not None:
+            first, second, second_key, bound = hbm, valu, "valu_fp32", "latency"
+            note = ("k_whitted with photon lookups, rank 0's launches. Algorithmic bytes: 32 B per kd-tree node a lookup visits (the "
+                    "reference's visits: same tree, same order) plus the frame's ray bytes. A lookup is a chain of dependent 32-byte "
+                    "fetches whose order the reference's heap fixes; lanes of a wave are at unrelated nodes of unrelated lookups, so "
+                    "the kernel is held by that chain's latency at a few active lanes per instruction, far from HBM's rate.")
+        elif mode == abi.RT_MODE_WHITTED:
+            first, second, second_key, bound = valu, hbm, "hbm", "valu_fp32"
+            note = ("k_whitted, one launch per frame. Algorithmic flops price every ray against every object of the scene, as the "
+                    "reference does it (hand counts per ray-node transform and primitive test); the kernel itself walks a hierarchy "
+                    "over the objects' boxes and tests between one and two of the 66 objects per ray (measured with a diagnostic build "
+                    "that counts them: with such a library `executed` holds the figure priced on the object tests made; the "
+                    "hierarchy's own box tests are not priced). The scene's records come through the scalar "
+                    "cache; HBM sees the frame planes only.")
+        else:
+            first, second, second_key, bound = valu, hbm, "hbm", "valu_fp32"
+            note = ("k_paths, one launch per frame: the one-kernel form of the path tracer for scenes without meshes. Algorithmic "
+                    "flops price every ray against every object, as the reference does it (scenes of sixteen objects and more are walked "
+                    "through a hierarchy over the objects' boxes: `executed`, from a diagnostic build, prices the object tests made); un-fused FP32 (the code is built without "
+                    "contraction so that its results are the reference's bit for bit) can reach a quarter of the packed-FMA peak "
+                    "the fraction is taken against. The scene's records come through the scalar cache; HBM sees the sample buffer.")
+        roof = dict(first, bound=bound, traffic=traffic, traffic_source=traffic_src,
+                    kernel=kernel, avg_launch_ms=avg_launch_s * 1e3, launches_per_frame=n_launch,
+                    kernel_ms_per_frame=kernel_ms / args.steps,
+                    box_tests_per_frame=int(stats[3].item()), tri_tests_per_frame=int(stats[4].item()),
+                    note=note, **{second_key: second})
+        if traffic:
+            roof["traffic_gbps"] = traffic / avg_launch_s / 1e9
+        if issue:
+            roof["issue"] = issue
+        if c.phase_cycles[10] and ntri == 0:  # a build that counts the object tests its scene walks make (the last timed frame's)
+            ex = algorithmic_flops(hs.desc, c, mode, object_tests=c.phase_cycles[10]) / n_launch
+            roof["executed"] = {"object_tests_per_ray": c.phase_cycles[10] / max(1, c.closest_rays + c.shadow_rays),
+                                "gflop_per_launch": ex / 1e9, "achieved": ex / avg_launch_s / 1e12, "unit": "TFLOP/s",
+                                "frac": ex / avg_launch_s / 1e12 / PEAK_FP32_TFLOPS}
         out = {
             "metric": METRICS[args.workload],
             "value": rays_per_frame * args.steps / dt / 1e6,
@@ -357,16 +413,7 @@ def main():
                        "max_bounces": prm.max_bounces, "mode": "path" if mode == abi.RT_MODE_PATH else "whitted",
                        "parallelism": f"tiles/{world}", "rays_per_frame": int(rays_per_frame),
                        "camera_paths_per_frame": int(stats[2].item())},
-            "roofline": dict(first, bound="hbm" if mem_bound else "valu_fp32", traffic=traffic, traffic_source=traffic_src,
-                             kernel=kernel, avg_launch_ms=avg_launch_s * 1e3, launches_per_frame=n_launch,
-                             kernel_ms_per_frame=kernel_ms / args.steps,
-                             box_tests_per_frame=int(stats[3].item()), tri_tests_per_frame=int(stats[4].item()),
-                             note="rank 0's launches; algorithmic bytes and flops from the kernels' own ray/box/triangle/photon counters "
-                                  "(the counting variant walks the reference's binary BVH, so the box and triangle tests are the reference's). "
-                                  "The peak is HBM's, but the BVH and triangle pools (about 90 MB for 1M triangles) stay resident in the 256 MiB "
-                                  "Infinity Cache: the memory-side counters behind `traffic` see fabric requests served from it, not DRAM reads. "
-                                  "What limits the ray kernel is VALU issue at about half-filled waves and the L1's rate for divergent 16-byte reads.",
-                             **{second_key: second}),
+            "roofline": roof,
         }
         if pp:
             out["photons"] = {"global": pp.n_global, "caustics": pp.n_caustic, "paths": photon_stats.get("paths"),

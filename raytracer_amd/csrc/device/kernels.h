@@ -70,6 +70,9 @@ RT_DEV void flush_counters(DCounters *ctr, const PathTally &pt, const Tally<COUN
 #ifdef RT_CULL_CHECK
     { const uint64_t cv = wave_sum(tl.cull_violations); if ((threadIdx.x & 63) == 0) atomicAdd(&ctr->phase[11], (unsigned long long)cv); }
 #endif
+#ifdef RT_COUNT_OBJECTS
+    { const uint64_t ob = wave_sum(tl.objects); if ((threadIdx.x & 63) == 0) atomicAdd(&ctr->phase[10], (unsigned long long)ob); }
+#endif
 #ifdef RT_PROFILE_LANES
     for (int i = 0; i < 8; ++i) {
         const uint64_t wv = wave_sum(tl.wave[i]), ln = wave_sum(tl.lanes[i]);

@@ -91,6 +91,12 @@ template <bool COUNT> struct Tally {
 #ifdef RT_CULL_CHECK
     uint32_t cull_violations = 0; // diagnostic build: objects the wave skipped although this lane's own box test said "reaches"
 #endif
+#ifdef RT_COUNT_OBJECTS
+    uint32_t objects = 0; // diagnostic build: sphere, plane and mesh tests this lane made (what the object hierarchy leaves of "every ray against every object")
+    RT_DEV void object() { ++objects; }
+#else
+    RT_DEV void object() {}
+#endif
     RT_DEV void boxes(uint32_t n) { if (COUNT) box += n; }
     RT_DEV void tris(uint32_t n) { if (COUNT) tri += n; }
 #ifdef RT_PROFILE_LANES
@@ -472,6 +478,7 @@ RT_DEV bool trace_closest(const DScene &S, Ray ray, LaneStack st, Hit &h, Tally<
             const int prim = nd.prim;
             float t = 0; int front = 1; bool ok = false;
             uint32_t face = 0; float u = 0, v = 0;
+            tl.object();
             if (prim == RT_PRIM_SPHERE) ok = sphere_t(lr, t, front);
             else if (prim == RT_PRIM_PLANE) ok = plane_t(lr, t, front);
             else {
@@ -499,6 +506,7 @@ RT_DEV bool trace_closest(const DScene &S, Ray ray, LaneStack st, Hit &h, Tally<
         if (prim == RT_PRIM_NONE || skip) continue;
         float t = 0; int front = 1; bool ok = false;
         uint32_t face = 0; float u = 0, v = 0;
+        tl.object();
         if (prim == RT_PRIM_SPHERE) ok = sphere_t(lr, t, front);
         else if (prim == RT_PRIM_PLANE) ok = plane_t(lr, t, front);
         else {
@@ -614,6 +622,7 @@ RT_DEV bool trace_shadow(const DScene &S, Ray ray, float t_max, LaneStack st, Ta
                 Ray lr = r0;
                 for (int k = 1; k <= nd.depth; ++k) lr = to_node(load_uniform(&S.nodes[nd.chain[k]]), lr);
                 const int prim = nd.prim;
+                tl.object();
                 if (prim == RT_PRIM_SPHERE) occluded = sphere_shadow(lr, t_max);
                 else if (prim == RT_PRIM_PLANE) occluded = plane_shadow(lr, t_max);
                 else occluded = mesh_shadow<COUNT>(load_uniform(&S.meshes[nd.mesh]), lr, t_max, st, tl);
@@ -637,6 +646,7 @@ RT_DEV bool trace_shadow(const DScene &S, Ray ray, float t_max, LaneStack st, Ta
         if (prim == RT_PRIM_NONE || skip) continue;
         if (CULL) {
             if (!occluded) {
+                tl.object();
                 if (prim == RT_PRIM_SPHERE) occluded = sphere_shadow(lr, t_max);
                 else if (prim == RT_PRIM_PLANE) occluded = plane_shadow(lr, t_max);
                 else occluded = mesh_shadow<COUNT>(load_uniform(&S.meshes[nd.mesh]), lr, t_max, st, tl);
@@ -644,6 +654,7 @@ RT_DEV bool trace_shadow(const DScene &S, Ray ray, float t_max, LaneStack st, Ta
             if (__all(occluded)) break;
         } else {
             bool occ;
+            tl.object();
             if (prim == RT_PRIM_SPHERE) occ = sphere_shadow(lr, t_max);
             else if (prim == RT_PRIM_PLANE) occ = plane_shadow(lr, t_max);
             else occ = mesh_shadow<COUNT>(load_uniform(&S.meshes[nd.mesh]), lr, t_max, st, tl);
