@@ -240,6 +240,50 @@ __global__ __launch_bounds__(kBlock) void k_lbvh_emit_binary(LbvhArrays A, const
     }
 }
 
+// A four-wide record is 64 bytes: the corner of the box around all its children, a power-of-two step per axis, the
+// children's data words, and the children's boxes as 8-bit multiples of the step from the corner - rounded outwards, so
+// a child's box in the record contains its real one:
+//   float4 0: corner x y z, w = bits: biased exponents of the steps, x | y << 8 | z << 16
+//   float4 1: bits: the four data words (0x7FFFFFFF: no child in this slot)
+//   float4 2: bits: min x, max x, min y, max y - each dword holds the four children's values, child k in byte k
+//   float4 3: bits: min z, max z, unused, unused
+// A ray's visit of a record is bounded by what the vector memory path delivers per lane, not by arithmetic: the 128-byte
+// record of full floats cost eight 16-byte loads per lane and visit, this one three and a half, and the boxes grow by
+// less than 1/254 of the record's own extent.
+constexpr uint32_t kWideNoChild = 0x7FFFFFFFu;
+RT_HD void wide_record_pack(const float box[4][6], const uint32_t word[4], uint32_t n, float4 rec[4])
+{
+    float corner[3], step[3];
+    uint32_t exps = 0, planes[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+    for (int a = 0; a < 3; ++a) {
+        float l = box[0][a], h = box[0][3 + a];
+        for (uint32_t k = 1; k < n; ++k) { l = box[k][a] < l ? box[k][a] : l; h = box[k][3 + a] > h ? box[k][3 + a] : h; }
+        corner[a] = l;
+        int e = 0;
+        (void)frexpf((h - l) / 254.0f, &e); // (h - l) / 254 = m 2^e with m in [0.5, 1): 254 steps of 2^e span the box, one is left for the rounding below
+        int biased = e + 127;
+        biased = biased < 1 ? 1 : biased > 254 ? 254 : biased;
+        exps |= (uint32_t)biased << (8 * a);
+        step[a] = __builtin_bit_cast(float, (uint32_t)biased << 23);
+    }
+    for (uint32_t k = 0; k < n; ++k)
+        for (int a = 0; a < 3; ++a) {
+            float ql = floorf((box[k][a] - corner[a]) / step[a]);
+            ql = ql < 0.0f ? 0.0f : ql > 255.0f ? 255.0f : ql;
+            if (ql > 0.0f && fmaf(ql, step[a], corner[a]) > box[k][a]) ql -= 1.0f; // (the difference above was rounded up)
+            float qh = ceilf((box[k][3 + a] - corner[a]) / step[a]);
+            qh = qh < 0.0f ? 0.0f : qh > 255.0f ? 255.0f : qh;
+            if (qh < 255.0f && fmaf(qh, step[a], corner[a]) < box[k][3 + a]) qh += 1.0f;
+            planes[2 * a] |= (uint32_t)ql << (8 * k);
+            planes[2 * a + 1] |= (uint32_t)qh << (8 * k);
+        }
+    const auto f = [](uint32_t u) { return __builtin_bit_cast(float, u); };
+    rec[0] = make_float4(corner[0], corner[1], corner[2], f(exps));
+    rec[1] = make_float4(f(n > 0 ? word[0] : kWideNoChild), f(n > 1 ? word[1] : kWideNoChild), f(n > 2 ? word[2] : kWideNoChild), f(n > 3 ? word[3] : kWideNoChild));
+    rec[2] = make_float4(f(planes[0]), f(planes[1]), f(planes[2]), f(planes[3]));
+    rec[3] = make_float4(f(planes[4]), f(planes[5]), 0.0f, 0.0f);
+}
+
 // The four-wide records, one level of the wide tree per launch, from the root down. A record starts from the two
 // children of its node and twice replaces the widest kept inner node among its slots (largest box area: the one a ray
 // is likeliest to enter) by that node's two children, so a record may reach three levels down one side of the binary
@@ -249,7 +293,6 @@ __global__ __launch_bounds__(kBlock) void k_lbvh_emit_binary(LbvhArrays A, const
 __global__ __launch_bounds__(kBlock) void k_lbvh_wide_level(LbvhArrays A, const uint32_t *__restrict__ inner_flag, const uint32_t *__restrict__ inner_rank,
                                                             uint32_t *__restrict__ front, uint32_t *__restrict__ count, uint32_t level, LbvhOut O)
 {
-    const float inf = __builtin_inff();
     uint32_t begin = 0;
     for (uint32_t l = 0; l < level; ++l) begin += count[l];
     const uint32_t n_here = count[level], next_begin = begin + n_here;
@@ -274,18 +317,18 @@ __global__ __launch_bounds__(kBlock) void k_lbvh_wide_level(LbvhArrays A, const 
         uint32_t n_inner = 0;
         for (uint32_t k = 0; k < ns; ++k) n_inner += !(slots[k] & kLbvhLeaf) && inner_flag[slots[k]] ? 1u : 0u;
         uint32_t next = n_inner ? next_begin + atomicAdd(&count[level + 1], n_inner) : 0u;
-        float4 *rec = O.recs + (size_t)r * 8;
-        for (uint32_t k = 0; k < 4; ++k) {
-            if (k < ns) {
-                const float *box; bool inner;
-                uint32_t w = lbvh_child_word(A, inner_rank, inner_flag, slots[k], O, box, inner);
-                if (inner) { front[next] = slots[k]; w = O.rec_base + next++; }
-                lbvh_store_node(rec + k * 2, box, w);
-            } else { // a box no ray enters
-                rec[k * 2] = make_float4(inf, inf, inf, inf);
-                rec[k * 2 + 1] = make_float4(inf, inf, __uint_as_float(0x7FFFFFFFu), 0.0f);
-            }
+        float boxes[4][6];
+        uint32_t words[4] = {kWideNoChild, kWideNoChild, kWideNoChild, kWideNoChild};
+        for (uint32_t k = 0; k < ns; ++k) {
+            const float *box; bool inner;
+            uint32_t w = lbvh_child_word(A, inner_rank, inner_flag, slots[k], O, box, inner);
+            if (inner) { front[next] = slots[k]; w = O.rec_base + next++; }
+            words[k] = w;
+            for (int a = 0; a < 6; ++a) boxes[k][a] = box[a];
         }
+        float4 rec[4];
+        wide_record_pack(boxes, words, ns, rec);
+        for (int i = 0; i < 4; ++i) O.recs[(size_t)r * 4 + i] = rec[i];
     }
 }
 

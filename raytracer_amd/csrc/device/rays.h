@@ -106,12 +106,6 @@ struct BriefIO {
 #ifndef RT_RAYS_REFILL_MIN_LANES
 #define RT_RAYS_REFILL_MIN_LANES 24 // fetch new rays once this many lanes are idle
 #endif
-// Records of the four-wide BVH kept in LDS by the ray-list kernel: the top levels of the scene's largest mesh, which
-// every ray of it passes (85 = three full levels; 0 builds the cache out)
-#ifndef RT_TOP4_RECORDS
-#define RT_TOP4_RECORDS 0
-#endif
-constexpr int kTop4Records = RT_TOP4_RECORDS;
 constexpr uint32_t kRayChunk = 256; // rays a wave reserves per queue atomic unless the launch says otherwise
 constexpr uint32_t kNoNode = 0x7FFFFFFFu; // not a data word: an inner node's first child index is far smaller
 
@@ -265,7 +259,7 @@ template <bool COUNT, int LEVELS, class IO> struct RayWalker {
 
     // The scene pass, if enough lanes wait for it, then BVH steps while enough lanes are inside a mesh.
     // Called by the whole wave; every call makes progress if any lane has a ray.
-    RT_DEV void phases(const DScene &S, const IO &io, const LaneStack &st, const f4 *top4, PathTally &pt, Tally<COUNT> &tl)
+    RT_DEV void phases(const DScene &S, const IO &io, const LaneStack &st, PathTally &pt, Tally<COUNT> &tl)
     {
         const float epsilon = 1e-6f;
         const GF4 bvh = (GF4)S.bvh_pool, tris = (GF4)(kWide ? S.tri4_pool : S.tri_pool);
@@ -376,27 +370,36 @@ template <bool COUNT, int LEVELS, class IO> struct RayWalker {
             if (cur != kNoNode) {
                 if (cur & kLeafBit) { at_leaf = true; leaf_data = cur; leaf_i = 0; cur = kNoNode; }
                 else if (kWide) {
-                    f4 a0, a1, b0, b1, c0, c1, e0, e1;
-                    const uint32_t above = cur - S.top4_base; // place among the records kept in LDS, if it is one
-                    if (kTop4Records > 0 && above < S.top4_count) {
-                        const f4 *rec = top4 + above * 8;
-                        a0 = rec[0]; a1 = rec[1]; b0 = rec[2]; b1 = rec[3]; c0 = rec[4]; c1 = rec[5]; e0 = rec[6]; e1 = rec[7];
-                    } else {
-                        const GF4 rec = (GF4)S.bvh4_pool + (size_t)cur * 8;
-                        a0 = rec[0]; a1 = rec[1]; b0 = rec[2]; b1 = rec[3]; c0 = rec[4]; c1 = rec[5]; e0 = rec[6]; e1 = rec[7];
-                    }
+                    // the record (device/lbvh.h: wide_record_pack): three and a half 16-byte loads
+                    const GF4 rec = (GF4)S.bvh4_pool + (size_t)cur * 4;
+                    const f4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+                    const f2 r3 = *(const RT_GLOBAL_AS f2 *)(rec + 3);
+                    const uint32_t eb = __float_as_uint(r0.w);
+                    const V3 step = mk(__uint_as_float((eb & 0xFFu) << 23), __uint_as_float(((eb >> 8) & 0xFFu) << 23), __uint_as_float(((eb >> 16) & 0xFFu) << 23));
+                    const uint32_t lox = __float_as_uint(r2.x), hix = __float_as_uint(r2.y), loy = __float_as_uint(r2.z), hiy = __float_as_uint(r2.w);
+                    const uint32_t loz = __float_as_uint(r3.x), hiz = __float_as_uint(r3.y);
+                    uint32_t k0 = __float_as_uint(r1.x), k1 = __float_as_uint(r1.y), k2 = __float_as_uint(r1.z), k3 = __float_as_uint(r1.w);
                     float d0, d1, d2, d3;
                     bool h0, h1, h2, h3;
-                    if (__builtin_expect(exact, 0)) { // (one branch around the four tests, not one in each)
-                        h0 = bvh_box_exact(lr.p, inv, t_limit, a0, a1, d0); h1 = bvh_box_exact(lr.p, inv, t_limit, b0, b1, d1);
-                        h2 = bvh_box_exact(lr.p, inv, t_limit, c0, c1, d2); h3 = bvh_box_exact(lr.p, inv, t_limit, e0, e1, d3);
+                    if (__builtin_expect(exact, 0)) { // (one branch around the four tests, not one in each) the boxes as floats, then the reference's test
+                        const auto child = [&](int k, float &dist) {
+                            const auto q = [k](uint32_t plane) { return (float)((plane >> (8 * k)) & 0xFFu); };
+                            const f4 b0 = {r0.x + q(lox) * step.x, r0.x + q(hix) * step.x, r0.y + q(loy) * step.y, r0.y + q(hiy) * step.y};
+                            const f4 b1 = {r0.z + q(loz) * step.z, r0.z + q(hiz) * step.z, 0.0f, 0.0f};
+                            return bvh_box_exact(lr.p, inv, t_limit, b0, b1, dist);
+                        };
+                        h0 = child(0, d0); h1 = child(1, d1); h2 = child(2, d2); h3 = child(3, d3);
                     } else {
-                        h0 = bvh_box_fast(lr.p, inv, t_limit, a0, a1, d0); h1 = bvh_box_fast(lr.p, inv, t_limit, b0, b1, d1);
-                        h2 = bvh_box_fast(lr.p, inv, t_limit, c0, c1, d2); h3 = bvh_box_fast(lr.p, inv, t_limit, e0, e1, d3);
+                        // t at a child's plane q: ((corner + q step) - p) inv = (corner - p) inv + q (step inv)
+                        const V3 at = mk((r0.x - lr.p.x) * inv.x, (r0.y - lr.p.y) * inv.y, (r0.z - lr.p.z) * inv.z);
+                        const V3 per = mk(step.x * inv.x, step.y * inv.y, step.z * inv.z);
+                        h0 = wide_box_fast<0>(at, per, t_limit, lox, hix, loy, hiy, loz, hiz, d0);
+                        h1 = wide_box_fast<1>(at, per, t_limit, lox, hix, loy, hiy, loz, hiz, d1);
+                        h2 = wide_box_fast<2>(at, per, t_limit, lox, hix, loy, hiy, loz, hiz, d2);
+                        h3 = wide_box_fast<3>(at, per, t_limit, lox, hix, loy, hiy, loz, hiz, d3);
                     }
-                    h0 = h0 && d0 < t_limit; h1 = h1 && d1 < t_limit; h2 = h2 && d2 < t_limit; h3 = h3 && d3 < t_limit;
-                    uint32_t k0 = __float_as_uint(a1.z), k1 = __float_as_uint(b1.z), k2 = __float_as_uint(c1.z), k3 = __float_as_uint(e1.z);
-                    // boxes the ray does not enter sort to the end
+                    // (a box is entered before its far side, and the far side is cut at t_limit: no further test against
+                    // t_limit) boxes the ray does not enter, and slots without a child, sort to the end
                     d0 = h0 && k0 != kNoNode ? d0 : INFINITY; d1 = h1 && k1 != kNoNode ? d1 : INFINITY;
                     d2 = h2 && k2 != kNoNode ? d2 : INFINITY; d3 = h3 && k3 != kNoNode ? d3 : INFINITY;
                     const auto order = [](float &da, uint32_t &ka, float &db, uint32_t &kb) {
@@ -524,14 +527,6 @@ __global__ __launch_bounds__(kBlock, RT_RAYS_MIN_WAVES) void k_rays(DScene S, IO
     PathTally pt;
     Tally<COUNT> tl;
     RayWalker<COUNT, LEVELS, IO> w;
-    // the top of the wide BVH behind the stacks
-    f4 *top4 = (f4 *)(lds + (size_t)S.lds_levels * kStackStride * 2);
-    if (kTop4Records > 0 && RayWalker<COUNT, LEVELS, IO>::kWide && S.top4_count != 0) {
-        const GF4 src = (GF4)S.bvh4_pool + (size_t)S.top4_base * 8;
-        for (uint32_t i = threadIdx.x; i < S.top4_count * 8; i += kBlock) top4[i] = src[i];
-        __syncthreads();
-    }
-
     // The list is handed out in portions of ray_chunk entries, one global atomic per portion; a portion belongs to the
     // WORKGROUP, whose waves draw their rays from it as their lanes fall idle (one LDS atomic per refill).  A portion
     // is a few neighbouring pixels' rays, and cost is a matter of place (rays along a mesh's rim take fifteen times
@@ -630,7 +625,7 @@ __global__ __launch_bounds__(kBlock, RT_RAYS_MIN_WAVES) void k_rays(DScene S, IO
             if (exhausted) break; // every wave gets here: the queue word only grows
             continue;
         }
-        w.phases(S, io, st, top4, pt, tl);
+        w.phases(S, io, st, pt, tl);
     }
     if (IO::kDeferShadow && w.unoccluded) { typename IO::Pending pend; io.begin_put_shadow(w.tag, pend); io.end_put_shadow(w.tag, pend); }
     if (w.finished) w.finish_closest(S, io);

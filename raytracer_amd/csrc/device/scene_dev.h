@@ -106,7 +106,6 @@ struct DScene {
     float environment[3]; // what a secondary ray of the Whitted-style shader sees when it leaves the scene
     int32_t stack_levels; // BVH stack entries a lane may need (deepest mesh + 2), 0 without meshes
     int32_t lds_levels;   // of which in LDS; the rest in stack_overflow
-    uint32_t top4_base, top4_count; // four-wide BVH records [top4_base, top4_base + top4_count): the top levels of the largest mesh, in breadth-first order, which the ray-list kernel keeps in LDS
     uint2 *gather_heaps;   // [photon-lookup slots of the largest grid][66]: last level of the slots' heaps of nearest photons
     uint32_t *gather_ids;  // [slots][128]: the photons found
     uint2 *stack_overflow; // [(stack_levels - lds_levels)][threads of the largest grid]

@@ -233,6 +233,21 @@ RT_DEV bool bvh_box_fast(V3 p, V3 inv, float t_max, f4 b0, f4 b1, float &dist)
     dist = tNear;
     return tNear < tFar;
 }
+// The same test for child K of a four-wide record (device/lbvh.h: wide_record_pack), in the ray's own parameter:
+// `at` is t at the record's corner plane per axis, `per` the change of t per step; the planes hold the children's
+// 8-bit plane positions, child K in byte K.
+template <int K>
+RT_DEV bool wide_box_fast(V3 at, V3 per, float t_max, uint32_t lox, uint32_t hix, uint32_t loy, uint32_t hiy, uint32_t loz, uint32_t hiz, float &dist)
+{
+    const auto q = [](uint32_t plane) { return (float)((plane >> (8 * K)) & 0xFFu); };
+    const f2 tx = __builtin_elementwise_fma(f2{q(lox), q(hix)}, f2{per.x, per.x}, f2{at.x, at.x});
+    const f2 ty = __builtin_elementwise_fma(f2{q(loy), q(hiy)}, f2{per.y, per.y}, f2{at.y, at.y});
+    const f2 tz = __builtin_elementwise_fma(f2{q(loz), q(hiz)}, f2{per.z, per.z}, f2{at.z, at.z});
+    const float tNear = vmax(vmax3(vmin(tx.x, tx.y), vmin(ty.x, ty.y), vmin(tz.x, tz.y)), 0.0f);
+    const float tFar = vmin(vmin3(vmax(tx.x, tx.y), vmax(ty.x, ty.y), vmax(tz.x, tz.y)), t_max);
+    dist = tNear;
+    return tNear < tFar;
+}
 RT_DEV bool bvh_box_exact(V3 p, V3 inv, float t_max, f4 b0, f4 b1, float &dist)
 {
     float tNear = 0.0f;

@@ -275,7 +275,7 @@ __global__ __launch_bounds__(kBlock) void k_wf_finish(DScene S, DFrame F, int k0
         if (keeper && have_path && goes_on) w.start(slot, make_float4(ray.p.x, ray.p.y, ray.p.z, 0.0f), make_float4(ray.d.x, ray.d.y, ray.d.z, 0.0f), false, 0.0f, pt);
         if (!keeper && sh) w.start(0, so, sd, true, so.w, pt);
         if (!__any(w.active)) break; // no pair has a path left, and the list is empty
-        while (__any(w.active)) w.phases(S, io, st, nullptr, pt, tl);
+        while (__any(w.active)) w.phases(S, io, st, pt, tl);
         // ---- the shadow ray's answer first (vertex b), then the new vertex (b + 1) ----
         const bool lit = __shfl((int)(!keeper && w.unoccluded), odd, 64) != 0;
         w.unoccluded = false;

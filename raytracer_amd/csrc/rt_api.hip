@@ -343,7 +343,7 @@ static int render_wavefront(rt_ctx *ctx, const DFrame &F, const int32_t *act, ui
 
     const void *fn = wf_trace_kernel(ctx->counting, scene_levels(ctx));
     int per_cu = 1;
-    const size_t lds_rays = lds + (ctx->counting ? 0 : (size_t)ctx->scene.top4_count * 128); // the top of the wide BVH behind the stacks
+    const size_t lds_rays = lds;
     HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kBlock, lds_rays));
     per_cu = std::max(1, std::min(per_cu, 8));
     DScene a_scene = ctx->scene;
@@ -678,7 +678,7 @@ static int build_bvh_gpu(rt_ctx *ctx, const rt_mesh &m, uint32_t node_base, uint
         // every kept inner node could be the root of a record; the wide tree has at most as many levels as the binary one
         if ((uint64_t)node_base + 2 + 2ull * T >= (1ull << 31) || (uint64_t)rec_base + T >= (1ull << 31)) return ctx->fail(RT_ERR_UNSUPPORTED, "scene has too many BVH nodes");
         out.n_nodes = 2 + 2 * T;
-        HIP_TRY(ctx, out.nodes->reserve((size_t)out.n_nodes * 32)); HIP_TRY(ctx, out.recs->reserve((size_t)T * 128));
+        HIP_TRY(ctx, out.nodes->reserve((size_t)out.n_nodes * 32)); HIP_TRY(ctx, out.recs->reserve((size_t)T * 64));
         HIP_TRY(ctx, hipMemsetAsync(out.nodes->p, 0, 64, s));
         O.nodes = out.nodes->as<float4>(); O.recs = out.recs->as<float4>();
         hipLaunchKernelGGL(k_lbvh_emit_binary, grid, block, 0, s, A, inner.as<uint32_t>(), inner_rank.as<uint32_t>(), O);
@@ -826,9 +826,8 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc)
     std::vector<float4> bvh(gpu_bvh ? 0 : pool_nodes * 2, make_float4(0, 0, 0, 0));
     std::vector<float4> tris(gpu_bvh ? 0 : pool_tris * 3);
     std::vector<rt_bvh_node> roots(sc->n_meshes);
-    std::vector<float4> bvh4; // records of eight float4
+    std::vector<float4> bvh4; // records of four float4 (device/lbvh.h: wide_record_pack)
     std::vector<uint32_t> root4(sc->n_meshes, 0);
-    size_t top4_mesh_records = 0; uint32_t top4_base = 0, top4_count = 0;
     for (uint32_t mi = 0; mi < sc->n_meshes; ++mi) {
         const rt_mesh &m = sc->meshes[mi];
         for (size_t k = 0; k < (size_t)m.nf * 3; ++k)
@@ -885,47 +884,35 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc)
             max_wide_levels = std::max(max_wide_levels, ((int)depth + 1) / 2); // a record per two levels
             const auto pooled = [&](uint32_t id) { return __builtin_bit_cast(uint32_t, bvh[(size_t)(nb + id) * 2 + 1].z); }; // data word, pool numbering
             const auto is_leaf = [&](uint32_t id) { return (m.bvh_nodes[id].data & 0x80000000u) != 0; };
-            const float inf = std::numeric_limits<float>::infinity();
             std::vector<std::pair<uint32_t, size_t>> todo; // (binary node, its record)
             const auto record_of = [&](uint32_t id) -> uint32_t { // data word of binary node `id` in the four-wide form
                 if (is_leaf(id)) return pooled(id);
-                const size_t rec = bvh4.size() / 8;
-                bvh4.resize(bvh4.size() + 8);
+                const size_t rec = bvh4.size() / 4;
+                bvh4.resize(bvh4.size() + 4);
                 todo.push_back({id, rec});
                 return (uint32_t)rec;
             };
-            const size_t first_rec = bvh4.size() / 8;
             root4[mi] = record_of(1);
-            size_t head = 0; // the first kTop4Records records of a mesh are its top levels in breadth-first order (first in, first out), the rest depth-first
-            while (head < todo.size()) {
-                const bool breadth = bvh4.size() / 8 - first_rec < (size_t)kTop4Records;
-                const auto [id, rec] = breadth ? todo[head] : todo.back();
-                if (breadth) ++head; else todo.pop_back();
+            while (!todo.empty()) { // depth-first: a record's children follow it closely
+                const auto [id, rec] = todo.back();
+                todo.pop_back();
                 const uint32_t c = m.bvh_nodes[id].data & 0x7FFFFFFFu;
                 uint32_t slots[4], ns = 0;
                 for (uint32_t ch = c; ch < c + 2; ++ch) {
                     if (is_leaf(ch)) slots[ns++] = ch;
                     else { const uint32_t g = m.bvh_nodes[ch].data & 0x7FFFFFFFu; slots[ns++] = g; slots[ns++] = g + 1; }
                 }
-                for (uint32_t k = 0; k < 4; ++k) {
-                    if (k < ns) {
-                        const uint32_t word = record_of(slots[k]); // may grow bvh4: index, not pointer
-                        const float4 b0 = bvh[(size_t)(nb + slots[k]) * 2], b1 = bvh[(size_t)(nb + slots[k]) * 2 + 1];
-                        bvh4[rec * 8 + k * 2] = b0;
-                        bvh4[rec * 8 + k * 2 + 1] = make_float4(b1.x, b1.y, __builtin_bit_cast(float, word), 0.0f);
-                    } else { // a box no ray enters
-                        bvh4[rec * 8 + k * 2] = make_float4(inf, inf, inf, inf);
-                        bvh4[rec * 8 + k * 2 + 1] = make_float4(inf, inf, __builtin_bit_cast(float, kNoNode), 0.0f);
-                    }
+                float boxes[4][6];
+                uint32_t words[4] = {kWideNoChild, kWideNoChild, kWideNoChild, kWideNoChild};
+                for (uint32_t k = 0; k < ns; ++k) {
+                    words[k] = record_of(slots[k]); // may grow bvh4: index, not pointer
+                    memcpy(boxes[k], m.bvh_nodes[slots[k]].bounds, sizeof boxes[k]);
                 }
+                float4 packed[4];
+                wide_record_pack(boxes, words, ns, packed);
+                for (int i = 0; i < 4; ++i) bvh4[rec * 4 + i] = packed[i];
             }
-            if (bvh4.size() / 8 >= ((size_t)1 << 31)) return ctx->fail(RT_ERR_UNSUPPORTED, "scene has too many BVH nodes");
-            const size_t n_rec = bvh4.size() / 8 - first_rec;
-            if (kTop4Records > 0 && !is_leaf(1) && n_rec > top4_mesh_records) { // the largest mesh's top levels go to LDS
-                top4_mesh_records = n_rec;
-                top4_base = (uint32_t)first_rec;
-                top4_count = (uint32_t)std::min<size_t>(n_rec, (size_t)kTop4Records);
-            }
+            if (bvh4.size() / 4 >= ((size_t)1 << 31)) return ctx->fail(RT_ERR_UNSUPPORTED, "scene has too many BVH nodes");
         }
         } // host-built BVH
         max_mesh_depth = std::max(max_mesh_depth, (int)depth);
@@ -961,14 +948,14 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc)
             return e;
         };
         HIP_TRY(ctx, pool(pool_nodes * 32, (const void **)&d_bvh_pool));
-        HIP_TRY(ctx, pool(pool_recs * 128, (const void **)&d_bvh4_pool));
+        HIP_TRY(ctx, pool(pool_recs * 64, (const void **)&d_bvh4_pool));
         HIP_TRY(ctx, pool(pool_tris * 48, (const void **)&d_tri_pool));
         HIP_TRY(ctx, hipMemset((void *)d_bvh_pool, 0, 64));
         size_t rec_at = 0;
         for (uint32_t mi = 0; mi < sc->n_meshes; ++mi) {
             GpuBvh &g = built[mi];
             HIP_TRY(ctx, hipMemcpy((char *)d_bvh_pool + (size_t)node_base[mi] * 32, g.nodes->p, (size_t)g.n_nodes * 32, hipMemcpyDeviceToDevice));
-            if (g.n_recs) HIP_TRY(ctx, hipMemcpy((char *)d_bvh4_pool + rec_at * 128, g.recs->p, (size_t)g.n_recs * 128, hipMemcpyDeviceToDevice));
+            if (g.n_recs) HIP_TRY(ctx, hipMemcpy((char *)d_bvh4_pool + rec_at * 64, g.recs->p, (size_t)g.n_recs * 64, hipMemcpyDeviceToDevice));
             HIP_TRY(ctx, hipMemcpy((char *)d_tri_pool + (size_t)tri_base[mi] * 48, g.tris->p, (size_t)sc->meshes[mi].nf * 48, hipMemcpyDeviceToDevice));
             rec_at += g.n_recs;
             g.nodes.reset(); g.recs.reset(); g.tris.reset();
@@ -988,19 +975,19 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc)
                 bufs.push_back(std::move(b));
                 return e;
             };
-            HIP_TRY(ctx, pool(pool_recs * 128, (const void **)&d_bvh4_pool));
+            HIP_TRY(ctx, pool(pool_recs * 64, (const void **)&d_bvh4_pool));
             HIP_TRY(ctx, pool(pool_tris * 48, (const void **)&d_tri4_pool));
             size_t rec_at = 0;
             for (uint32_t mi = 0; mi < sc->n_meshes; ++mi) {
                 GpuBvh &g = built[mi];
-                if (g.n_recs) HIP_TRY(ctx, hipMemcpy((char *)d_bvh4_pool + rec_at * 128, g.recs->p, (size_t)g.n_recs * 128, hipMemcpyDeviceToDevice));
+                if (g.n_recs) HIP_TRY(ctx, hipMemcpy((char *)d_bvh4_pool + rec_at * 64, g.recs->p, (size_t)g.n_recs * 64, hipMemcpyDeviceToDevice));
                 HIP_TRY(ctx, hipMemcpy((char *)d_tri4_pool + (size_t)tri_base[mi] * 48, g.tris->p, (size_t)sc->meshes[mi].nf * 48, hipMemcpyDeviceToDevice));
                 rec_at += g.n_recs;
                 g.nodes.reset(); g.recs.reset(); g.tris.reset();
             }
             ctx->bvh_build_ms = build_ms;
         } else {
-            if (bvh4.empty()) bvh4.resize(8, make_float4(0, 0, 0, 0));
+            if (bvh4.empty()) bvh4.resize(4, make_float4(0, 0, 0, 0));
             HIP_TRY(ctx, upload(bvh4.data(), bvh4.size() * sizeof(float4), (const void **)&d_bvh4_pool));
             d_tri4_pool = d_tri_pool;
             ctx->bvh_build_ms = 0;
@@ -1146,7 +1133,6 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc)
     S.tlas = tlas.empty() ? nullptr : ctx->d_tlas.as<TlasNode>();
     S.n_tlas = (int32_t)tlas.size();
     S.bvh_pool = d_bvh_pool; S.tri_pool = d_tri_pool; S.bvh4_pool = d_bvh4_pool; S.tri4_pool = d_tri4_pool;
-    S.top4_base = top4_base; S.top4_count = top4_count;
     S.cancel = (const uint32_t *)&ctx->host_words[0];
     S.progress = &ctx->host_words[1];
     HIP_TRY(ctx, ctx->d_meshes.reserve(sizeof(DMesh) * std::max<size_t>(1, dmeshes.size())));
