@@ -1206,11 +1206,7 @@ int rt_render(rt_ctx *ctx, const rt_render_params *prm, rt_frame_out *out)
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_halton.p, hal, sizeof hal, hipMemcpyHostToDevice, s));
 
     // pixel list of this shard in tile order (src/main.cpp:278-288), cached per image/tile geometry
-    // (RT_SPREAD: experiment - the wavefront pipeline's list dealt with a large stride, so that the pixels of one
-    // portion of the ray list come from far-apart places of the image)
-    static const int spread_env = getenv("RT_SPREAD") ? atoi(getenv("RT_SPREAD")) : 0;
-    const bool spread = spread_env != 0 && prm->mode == RT_MODE_PATH && prm->max_bounces > 0 && (ctx->pipeline == 1 || (ctx->pipeline < 0 && ctx->have_meshes));
-    const int key[6] = {W, H, prm->tile_size, prm->tile_rank, prm->tile_world, spread ? 1 : 0};
+    const int key[6] = {W, H, prm->tile_size, prm->tile_rank, prm->tile_world, 0};
     if (memcmp(key, ctx->active_key, sizeof key) != 0) {
         const int ts = prm->tile_size;
         const int tx = (W + ts - 1) / ts, ty = (H + ts - 1) / ts;
@@ -1219,14 +1215,6 @@ int rt_render(rt_ctx *ctx, const rt_render_params *prm, rt_frame_out *out)
             const int x0 = (t % tx) * ts, y0 = (t / tx) * ts;
             const int tw = std::min(ts, W - x0), th = std::min(ts, H - y0);
             for (int j = y0; j < y0 + th; ++j) for (int i = x0; i < x0 + tw; ++i) ctx->active_host.push_back(j * W + i);
-        }
-        if (spread && ctx->active_host.size() > 64) {
-            const uint64_t n = ctx->active_host.size();
-            uint64_t stride = (uint64_t)((double)n * 0.3819660113) | 1u;
-            while (std::__gcd(stride, n) != 1) stride += 2;
-            std::vector<int32_t> dealt(n);
-            for (uint64_t i = 0; i < n; ++i) dealt[i] = ctx->active_host[(i * stride) % n];
-            ctx->active_host.swap(dealt);
         }
         // the shard's whole list stays on the device (8 MB at 1080p: a millisecond of upload per frame otherwise); the
         // first sampling round reads it, the later rounds' shrinking lists alternate between the two d_active buffers
@@ -1298,8 +1286,7 @@ int rt_render(rt_ctx *ctx, const rt_render_params *prm, rt_frame_out *out)
     const int32_t *first_list = ctx->d_active_all.as<int32_t>();
     const bool order = ctx->order_pixels < 0 ? prm->tile_world > 1 : ctx->order_pixels != 0;
     const bool wavefront_frame = prm->mode == RT_MODE_PATH && prm->max_bounces > 0 && (ctx->pipeline == 1 || (ctx->pipeline < 0 && ctx->have_meshes));
-    static const bool order_wave = getenv("RT_ORDER_WAVE") && atoi(getenv("RT_ORDER_WAVE")) != 0;
-    if ((order || (order_wave && wavefront_frame)) && prm->mode == RT_MODE_PATH && prm->max_bounces > 0 && n0 > 1 && (!wavefront_frame || order_wave)) { // (the wavefront pipeline has all paths of a round in flight at once: nothing to order)
+    if (order && prm->mode == RT_MODE_PATH && prm->max_bounces > 0 && n0 > 1 && !wavefront_frame) { // (the wavefront pipeline has all paths of a round in flight at once: nothing to order)
         HIP_TRY(ctx, ctx->d_active_sorted.reserve(sizeof(int32_t) * n0));
         for (auto &b : ctx->d_keys) HIP_TRY(ctx, b.reserve(sizeof(uint32_t) * n0));
         const void *fn = ctx->ray_levels <= 1 ? (const void *)k_order_keys<1> : ctx->ray_levels == 2 ? (const void *)k_order_keys<2> : (const void *)k_order_keys<5>;
