@@ -236,15 +236,19 @@ def ulp_distance(a, b):
 
 
 @pytest.mark.gpu
-def test_wide_walk_against_the_references_rays():
+@pytest.mark.parametrize("own_tree", ["1", "0"], ids=["tree built on the GPU", "the reference's tree in four-wide records"])
+def test_wide_walk_against_the_references_rays(own_tree):
     """The four-wide BVH walk - what every extension and shadow ray of a mesh frame goes through, and what the
     bit-exact tests above bypass (they use the binary walk, as the depth / id planes do) - on the reference's own
     rays of the 1 M- and the 10 M-triangle scene and of the small mesh: the object hit must be the reference's for
     every ray, every shadow answer too, and t may differ from the reference's by one ulp in at most two rays per set
     (the wide walk takes children in distance order, so a box can be pruned against another "closest so far";
-    observed: one camera ray in twelve million)."""
+    observed: one camera ray in twelve million).  Both sources of the four-wide records: the tree the library builds
+    for the frames' rays, and the reference's binary tree collapsed (RT_WIDE_GPU_BVH=0); either way the children's boxes
+    are the 8-bit ones of the 64-byte records, rounded outwards."""
     mp = pytest.MonkeyPatch()
     mp.setenv("RT_QUERY_WIDE", "1")
+    mp.setenv("RT_WIDE_GPU_BVH", own_tree)
     wide = lib.Context(0)
     mp.undo()
     try:
