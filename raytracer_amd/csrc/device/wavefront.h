@@ -318,7 +318,10 @@ __global__ __launch_bounds__(kBlock) void k_wf_finish(DScene S, DFrame F, int k0
     flush_counters<COUNT>(ctr, pt, tl, 0);
 }
 
-constexpr uint32_t kShadeRounds = 8;                      // paths per lane and chunk
+#ifndef RT_SHADE_ROUNDS
+#define RT_SHADE_ROUNDS 8
+#endif
+constexpr uint32_t kShadeRounds = RT_SHADE_ROUNDS;        // paths per lane and chunk
 constexpr uint32_t kShadeChunk = kShadeRounds * kBlock;   // paths a workgroup orders by what they hit
 constexpr uint32_t kShadeBins = 64;                       // nothing, lights, then the scene's nodes (the last bin takes the rest)
 
