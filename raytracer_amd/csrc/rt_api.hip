@@ -1313,7 +1313,7 @@ int rt_render(rt_ctx *ctx, const rt_render_params *prm, rt_frame_out *out)
     // BVH walk full); scenes of spheres and planes, where every ray costs the same, through the lock-step path kernel
     const bool has_mesh = ctx->have_meshes;
     const bool wavefront = prm->mode == RT_MODE_PATH && prm->max_bounces > 0 && (ctx->pipeline == 1 || (ctx->pipeline < 0 && has_mesh));
-    const uint64_t kMaxItems = wavefront ? 1ull << 27 : 1ull << 28; // bounds the sample buffer to 4 GiB (the wavefront's path state to 18 GiB)
+    const uint64_t kMaxItems = wavefront ? 1ull << 27 : 1ull << 28; // bounds the sample buffer to 4 GiB (the wavefront's path state to 24 GiB)
     uint32_t n_active = n0;
     int cur = 0, k0 = 0;
     while (n_active > 0 && k0 < prm->max_spp) {
