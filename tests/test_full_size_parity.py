@@ -203,6 +203,29 @@ def test_config_c_band_vs_reference(ctx):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode,bounces", [(abi.RT_MODE_WHITTED, 0), (abi.RT_MODE_PATH, 50)], ids=["Whitted shader", "path tracer"])
+def test_config_b_band_at_full_size(ctx, mode, bounces):
+    """The 64-sphere configuration at its own size, 1920x1080 x 16 spp (the kernels walk the hierarchy over the objects'
+    boxes there, and a frame is a single launch of two million pixels): the GPU renders the whole frame, the oracle -
+    which tests every object, as the reference does - rows 536..551 of it; ids and depth of the band bit for bit, the
+    image to the usual tolerance, ray counts of the band's share within half a percent."""
+    from raytracer_amd import scenes
+    w, h, spp, y0, y1 = 1920, 1080, 16, 536, 552
+    hs = lib.HostScene.from_string(scenes.spheres_scene_xml(grid=8, width=w, height=h))
+    prm = abi.default_params(seed=3, min_spp=spp, max_spp=spp, max_bounces=bounces, mode=mode)
+    ctx.upload(hs.desc)
+    ctx.set_camera(hs.camera, w, h)
+    fr = ctx.render(prm)
+    cpu = O.render(hs, prm, w, h, y0=y0, y1=y1)
+    assert len(np.unique(cpu.object_id[y0:y1])) > 10, "the band should cross many spheres"
+    assert np.array_equal(fr.object_id[y0:y1], cpu.object_id[y0:y1]), "primary-hit ids"
+    assert np.array_equal(bits(fr.z[y0:y1]), bits(cpu.z[y0:y1])), "z-buffer"
+    assert np.array_equal(fr.sample_count[y0:y1], cpu.sample_count[y0:y1])
+    p = O.psnr(fr.rgb[y0:y1], cpu.rgb[y0:y1])
+    assert p >= PSNR_MIN, f"PSNR {p:.2f} dB vs the oracle's band"
+
+
+@pytest.mark.gpu
 def test_config_e_vs_reference(ctx):
     """The 10M-triangle scene at 3840x2160 with 16..256 adaptive samples: aimed rays bit for bit, and rows 832..847 of
     the whole frame (ids, z; sample counts and image within the tolerance of the adaptive goldens)."""
