@@ -363,6 +363,11 @@ __global__ __launch_bounds__(kBlock) void k_wf_shade(DScene S, DFrame F, const i
     // not all of them.  Every path's arithmetic is its own, so the order changes no result.
     const uint32_t chunk_first = chunk * kShadeChunk;
     const uint32_t chunk_n = n_in - chunk_first < kShadeChunk ? n_in - chunk_first : kShadeChunk;
+    // (Not the camera rays' hits: a chunk of them is a few neighbouring pixels' samples, which hit the same things.)
+    if (FIRST) {
+#pragma unroll
+        for (uint32_t r = 0; r < kShadeRounds; ++r) s_order[r * kBlock + threadIdx.x] = chunk_first + r * kBlock + threadIdx.x;
+    } else {
     uint32_t my_key[kShadeRounds], my_rank[kShadeRounds];
 #pragma unroll
     for (uint32_t r = 0; r < kShadeRounds; ++r) {
@@ -386,6 +391,7 @@ __global__ __launch_bounds__(kBlock) void k_wf_shade(DScene S, DFrame F, const i
     for (uint32_t r = 0; r < kShadeRounds; ++r) {
         const uint32_t i = r * kBlock + threadIdx.x;
         if (i < chunk_n) s_order[s_bin[my_key[r]] + my_rank[r]] = chunk_first + i;
+    }
     }
     __syncthreads();
     for (uint32_t r = 0; r < kShadeRounds; ++r) { // every lane takes every trip: the appends are workgroup-wide
