@@ -2,15 +2,13 @@
 // with ray-level regeneration: a lane that finishes its ray takes the next one from
 // the list at once, so the lanes of a wave stay busy although rays need anything from
 // 3 to 60 BVH node visits (src/main.cpp:16-125, src/TriObj.cpp:12-229).  The lane
-// carries nothing but its walk, so the kernel runs at high occupancy: while a ray is
-// inside a mesh the lane keeps the ray in the mesh's space only; when it comes out, the
-// world-space ray is read again from the list.
+// carries its ray (world space, and the space of the mesh it is in), its walk and the best
+// hit so far: about forty registers of state, four waves per SIMD.
 //
 // Where rays come from and where answers go is a policy (IO): a plain list for the batch
 // query entry points (RayListIO, BriefIO below), the path state of the wavefront renderer (wavefront.h).
 //   bool fetch(e, split, o, d, any_hit, t_max, tag)   entry e of the list; false = no ray there.  tag is what
 //                                              the lane keeps of the entry (whatever the other calls need)
-//   void refetch(tag, any_hit, o, d)           the same ray again
 //   void put_closest(tag, t, node, face, front, u, v)   t = FLT_MAX, node = -1: nothing hit
 //   void put_shadow(tag, occluded)
 //   kDeferShadow, Pending, begin_put_shadow(tag, pending), end_put_shadow(tag, pending): an IO that has to read
@@ -43,7 +41,6 @@ struct RayListIO {
         any_hit = !(o.w < 0.0f); t_max = o.w; tag = e;
         return true;
     }
-    RT_DEV void refetch(uint32_t e, bool, float4 &o, float4 &d) const { o = ray_o[e]; d = ray_d[e]; }
     RT_DEV void put_closest(uint32_t e, float t, int node, uint32_t face, int front, float u, float v) const
     {
         hit[e] = make_float4(t, __uint_as_float((uint32_t)node), __uint_as_float(face | ((uint32_t)front << 31)), u);
@@ -409,10 +406,19 @@ template <bool COUNT, int LEVELS, class IO> struct RayWalker {
                         da = td; ka = tk;
                     };
                     order(d0, k0, d1, k1); order(d2, k2, d3, k3); order(d0, k0, d2, k2); order(d1, k1, d3, k3); order(d1, k1, d2, k2);
-                    // farthest first onto the stack, the nearest is visited next
-                    if (d3 < INFINITY) { st.push_named(sp, k3, d3); ++sp; }
-                    if (d2 < INFINITY) { st.push_named(sp, k2, d2); ++sp; }
-                    if (d1 < INFINITY) { st.push_named(sp, k1, d1); ++sp; }
+                    // farthest first onto the stack, the nearest is visited next.  While three more entries fit the LDS
+                    // levels all three are written, without a branch each, and the stack pointer moves past those that
+                    // count (the sort put them first, so what an entry that does not count leaves behind is written
+                    // over by the next one or lies above the top).
+                    if (__builtin_expect((uint32_t)sp + 3u <= st.lds_levels, 1)) {
+                        st.put_lds(sp, k3, d3); sp += d3 < INFINITY ? 1 : 0;
+                        st.put_lds(sp, k2, d2); sp += d2 < INFINITY ? 1 : 0;
+                        st.put_lds(sp, k1, d1); sp += d1 < INFINITY ? 1 : 0;
+                    } else {
+                        if (d3 < INFINITY) { st.push_named(sp, k3, d3); ++sp; }
+                        if (d2 < INFINITY) { st.push_named(sp, k2, d2); ++sp; }
+                        if (d1 < INFINITY) { st.push_named(sp, k1, d1); ++sp; }
+                    }
                     cur = d0 < INFINITY ? k0 : kNoNode;
                 } else {
                     const uint32_t c1 = cur & 0x7FFFFFFFu;

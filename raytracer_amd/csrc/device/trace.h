@@ -77,6 +77,8 @@ struct LaneStack {
         if ((uint32_t)sp < lds_levels) ((NamedLds)lds)[(uint32_t)sp * kStackStride] = e;
         else ((NamedGlobal)ovf)[(size_t)((uint32_t)sp - lds_levels) * ovf_stride] = e;
     }
+    // an entry at level sp, which the caller knows to be one of the LDS levels
+    RT_DEV void put_lds(int sp, uint32_t data, float dist) const { ((NamedLds)lds)[(uint32_t)sp * kStackStride] = u32x2{data, __float_as_uint(dist)}; }
     RT_DEV void pop_named(int sp, uint32_t &data, float &dist) const
     {
         u32x2 e;
