@@ -108,10 +108,10 @@ constexpr uint32_t kNoNode = 0x7FFFFFFFu; // not a data word: an inner node's fi
 
 // One lane's ray and its walk, and the steps a wave takes with them; the members live in registers.
 template <bool COUNT, int LEVELS, class IO> struct RayWalker {
-    // The walk goes through the four-wide form of the BVH (DScene::bvh4_pool): one 128-byte record gives the boxes of a
-    // node's grandchildren, the ones the ray enters are taken nearest first.  Half the dependent fetches of the binary
-    // walk, the same triangles: a leaf is reached if and only if the ray enters every box above it, and a box lies
-    // inside its parent's.  What can differ from the reference's order is which of several triangles hit at exactly the
+    // The walk goes through the four-wide BVH (DScene::bvh4_pool): one 64-byte record gives the boxes of up to four
+    // nodes two or three levels further down, the ones the ray enters are taken nearest first.  Half the dependent
+    // fetches of a binary walk, the same triangles: a leaf is reached if and only if the ray enters every box above it,
+    // and the record's 8-bit boxes contain the real ones.  What can differ from the reference's order is which of several triangles hit at exactly the
     // same distance is reported; t and the node never do.  The counting variant walks the binary tree, as the reference
     // does: its box and triangle counts are the reference's.  So do the batch query entry points, whose answers are the
     // reference's to the last bit: with two hits an ulp apart the order of the walk can decide which box is still

@@ -91,9 +91,9 @@ struct DScene {
     int32_t n_tlas;
     const float4 *bvh_pool;    // BVH nodes of all meshes
     const float4 *tri_pool;    // triangle records of all meshes
-    // Four-wide form of the same BVHs: a record is one 128-byte line holding up to four nodes in the 32-byte layout
-    // of bvh_pool - the grandchildren of a node of the binary tree (a child that is a leaf stands for itself).  The
-    // data word of an inner node is the index of its own record; unused places hold boxes no ray enters and kNoNode.
+    // Four-wide BVHs over the same triangles, which the frames' extension and shadow rays walk: 64-byte records of up
+    // to four children with 8-bit boxes (lbvh.h: wide_record_pack), four float4 per record.  The data word of an inner
+    // child is the index of its own record; a slot without a child holds 0x7FFFFFFF.
     const float4 *bvh4_pool;
     const float4 *tri4_pool;   // triangle records in the leaf order of the four-wide BVH (the same array as tri_pool when both forms are one tree)
     const DMesh *meshes;
