@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Is a surface-area-heuristic tree worth building?  The frames' four-wide walk over (a) the reference's mean-split tree,
+(b) a full-sweep SAH tree built here in numpy (every split position on every axis tried at every node: the quality a
+binned or clustering builder on the GPU could at best reach), both collapsed into four-wide records by the library
+(RT_WIDE_GPU_BVH=0), and (c) the tree the library builds on the GPU.  python tests/bench_sah_tree.py [quads_x quads_y w h spp]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from raytracer_amd import abi, lib, scenes  # noqa: E402
+
+
+def sah_tree(v, f, max_leaf):
+    tv = v[f]                                   # [nf, 3, 3]
+    lo, hi = tv.min(1), tv.max(1)
+    cen = 0.5 * (lo + hi)
+    nodes = [np.zeros(7, np.uint32), None]      # node 0 unused, root = 1
+    elements = []
+    todo = [(1, np.arange(len(f)))]
+
+    def area(l, h):
+        d = h - l
+        return d[..., 0] * d[..., 1] + d[..., 1] * d[..., 2] + d[..., 2] * d[..., 0]
+
+    def record(l, h, data):
+        w = np.zeros(7, np.uint32)
+        w[:3] = l.astype(np.float32).view(np.uint32); w[3:6] = h.astype(np.float32).view(np.uint32); w[6] = data
+        return w
+
+    while todo:
+        node, idx = todo.pop()
+        l, h = lo[idx].min(0), hi[idx].max(0)
+        n = len(idx)
+        if n <= max_leaf:
+            nodes[node] = record(l, h, 0x80000000 | ((n - 1) << 28) | len(elements))
+            elements.extend(idx.tolist())
+            continue
+        best = (np.inf, None, None)
+        for a in range(3):
+            o = idx[np.argsort(cen[idx, a], kind="stable")]
+            ll, lh = np.minimum.accumulate(lo[o], 0), np.maximum.accumulate(hi[o], 0)
+            rl, rh = np.minimum.accumulate(lo[o][::-1], 0)[::-1], np.maximum.accumulate(hi[o][::-1], 0)[::-1]
+            k = np.arange(1, n)
+            cost = area(ll[:-1], lh[:-1]) * k + area(rl[1:], rh[1:]) * (n - k)
+            i = int(np.argmin(cost))
+            if cost[i] < best[0]:
+                best = (cost[i], o, i + 1)
+        _, o, cut = best
+        c = len(nodes)
+        nodes.extend([None, None])
+        nodes[node] = record(l, h, c)
+        todo.append((c, o[:cut])); todo.append((c + 1, o[cut:]))
+    return np.stack(nodes), np.array(elements, np.uint32)
+
+
+def frames(hs, w, h, spp, env):
+    for k, val in env.items():
+        os.environ[k] = val
+    ctx = lib.Context(0)
+    for k in env:
+        del os.environ[k]
+    ctx.upload(hs.desc)
+    ctx.set_camera(hs.camera, w, h)
+    prm = abi.default_params(seed=1, min_spp=spp, max_spp=spp, max_bounces=50)
+    ctx.render(prm)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        ctx.render(prm)
+    ms = (time.perf_counter() - t0) / 5 * 1e3
+    c = ctx.counters()
+    ctx.close()
+    return ms, c.trace_kernel_ms
+
+
+def main():
+    a = [int(x) for x in sys.argv[1:]] or [250, 128, 960, 540, 8]
+    qx, qy, w, h, spp = a
+    mesh = scenes.heightfield(qx, qy)
+    hs = lib.HostScene.from_string(scenes.mesh_scene_xml("mesh.obj", w, h))
+    hs.set_mesh("mesh.obj", mesh["v"], mesh["vt"], mesh["f"])
+    print(f"{len(mesh['f'])} triangles, {w}x{h} x {spp} spp")
+    print("the library's own tree (built on the GPU)            %8.2f ms/frame, ray launches %8.2f ms" % frames(hs, w, h, spp, {}))
+    print("the reference's mean-split tree, collapsed            %8.2f ms/frame, ray launches %8.2f ms" % frames(hs, w, h, spp, {"RT_WIDE_GPU_BVH": "0"}))
+    m = hs.desc.meshes[0]
+    for max_leaf in (4, 2):
+        t0 = time.time()
+        nodes, elements = sah_tree(np.asarray(mesh["v"], np.float64), np.asarray(mesh["f"], np.int64), max_leaf)
+        nodes = np.ascontiguousarray(nodes, np.uint32); elements = np.ascontiguousarray(elements, np.uint32)
+        m.bvh_nodes = abi.C.cast(nodes.ctypes.data, abi.C.POINTER(abi.BvhNode)); m.n_bvh_nodes = len(nodes)
+        m.bvh_elements = elements.ctypes.data_as(abi.u32p); m.bvh_depth = abi.bvh_depth(nodes)
+        print(f"full-sweep SAH tree, <= {max_leaf} triangles per leaf (built in {time.time() - t0:.0f} s, depth {m.bvh_depth}), collapsed"
+              "  %8.2f ms/frame, ray launches %8.2f ms" % frames(hs, w, h, spp, {"RT_WIDE_GPU_BVH": "0"}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
