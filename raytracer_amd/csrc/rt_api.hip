@@ -616,6 +616,7 @@ static int build_bvh_gpu(rt_ctx *ctx, const rt_mesh &m, uint32_t node_base, uint
     }
     for (int a = 0; a < 3; ++a) { out.bounds[a] = lo[a]; out.bounds[3 + a] = hi[a]; }
     DeviceBuf d_v, d_f, keys[2], order[2], child, parent, leaf_parent, range, ibox, lbox, arrived, inner, inner_rank, front, level_count, maxd, tmp;
+    DeviceBuf unit, unit_count, unit_first, tsize, toff;
     HIP_TRY(ctx, d_v.reserve((size_t)m.nv * 12)); HIP_TRY(ctx, d_f.reserve((size_t)n * 12));
     HIP_TRY(ctx, hipMemcpyAsync(d_v.p, m.v, (size_t)m.nv * 12, hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemcpyAsync(d_f.p, m.f, (size_t)n * 12, hipMemcpyHostToDevice, s));
@@ -629,7 +630,9 @@ static int build_bvh_gpu(rt_ctx *ctx, const rt_mesh &m, uint32_t node_base, uint
     HIP_TRY(ctx, hipMemsetAsync(maxd.p, 0, 4, s));
     HIP_TRY(ctx, hipEventRecord(ctx->evk0, s));
     LbvhArrays A{};
-    A.v = d_v.as<float>(); A.f = d_f.as<uint32_t>(); A.n = n; A.max_leaf = max_leaf;
+    A.v = d_v.as<float>(); A.f = d_f.as<uint32_t>(); A.n_faces = n; A.n = n; A.max_leaf = max_leaf;
+    HIP_TRY(ctx, unit.reserve((size_t)n * 4)); HIP_TRY(ctx, tsize.reserve((size_t)n * 4)); HIP_TRY(ctx, toff.reserve((size_t)n * 4));
+    A.unit = unit.as<uint32_t>(); A.tsize = tsize.as<uint32_t>(); A.toff = toff.as<uint32_t>();
     A.keys = keys[0].as<unsigned long long>(); A.order = order[0].as<uint32_t>();
     A.child = child.as<uint2>(); A.parent = parent.as<uint32_t>(); A.leaf_parent = leaf_parent.as<uint32_t>(); A.range = range.as<uint2>();
     A.ibox = ibox.as<float>(); A.lbox = lbox.as<float>(); A.arrived = arrived.as<uint32_t>(); A.inner = inner.as<uint32_t>();
@@ -642,14 +645,39 @@ static int build_bvh_gpu(rt_ctx *ctx, const rt_mesh &m, uint32_t node_base, uint
         axes = LbvhAxes{{0ull, 0ull}};
         for (int i = 0; i < 63; ++i) axes.w[i / 32] |= (unsigned long long)(i % 3) << (2 * (i % 32));
     }
+    // an exclusive prefix sum of `count` values and its total
+    const auto prefix_sum = [&](uint32_t *values, uint32_t *sums, uint32_t count, uint32_t &total) -> int {
+        size_t bytes = 0;
+        HIP_TRY(ctx, rocprim::exclusive_scan(nullptr, bytes, values, sums, 0u, (size_t)count, rocprim::plus<uint32_t>(), s));
+        HIP_TRY(ctx, tmp.reserve(std::max<size_t>(1, bytes)));
+        HIP_TRY(ctx, rocprim::exclusive_scan(tmp.p, bytes, values, sums, 0u, (size_t)count, rocprim::plus<uint32_t>(), s));
+        uint32_t last[2] = {0, 0};
+        HIP_TRY(ctx, hipMemcpyAsync(&last[0], values + (count - 1), 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipMemcpyAsync(&last[1], sums + (count - 1), 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipStreamSynchronize(s));
+        total = last[0] + last[1];
+        return RT_OK;
+    };
+    // the units the tree is built over: pairs of consecutive faces that share an edge, and the faces that are left (device/lbvh.h)
+    const uint32_t slots = (n + 1) / 2;
+    uint32_t nu = 0;
+    HIP_TRY(ctx, unit_count.reserve((size_t)slots * 4)); HIP_TRY(ctx, unit_first.reserve((size_t)slots * 4));
+    hipLaunchKernelGGL(k_lbvh_unit_counts, grid, block, 0, s, A.f, n, unit_count.as<uint32_t>());
+    if (int rc = prefix_sum(unit_count.as<uint32_t>(), unit_first.as<uint32_t>(), slots, nu)) return rc;
+    hipLaunchKernelGGL(k_lbvh_units, grid, block, 0, s, A.f, n, unit_count.as<uint32_t>(), unit_first.as<uint32_t>(), A.unit);
+    A.n = nu;
     hipLaunchKernelGGL(k_lbvh_keys, grid, block, 0, s, A, lo[0], lo[1], lo[2], scale(0), scale(1), scale(2), axes);
     size_t tmp_bytes = 0;
     HIP_TRY(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys[0].as<unsigned long long>(), keys[1].as<unsigned long long>(),
-                                           order[0].as<uint32_t>(), order[1].as<uint32_t>(), (size_t)n, 0u, 63u, s));
+                                           order[0].as<uint32_t>(), order[1].as<uint32_t>(), (size_t)nu, 0u, 63u, s));
     HIP_TRY(ctx, tmp.reserve(std::max<size_t>(1, tmp_bytes)));
     HIP_TRY(ctx, rocprim::radix_sort_pairs(tmp.p, tmp_bytes, keys[0].as<unsigned long long>(), keys[1].as<unsigned long long>(),
-                                           order[0].as<uint32_t>(), order[1].as<uint32_t>(), (size_t)n, 0u, 63u, s));
+                                           order[0].as<uint32_t>(), order[1].as<uint32_t>(), (size_t)nu, 0u, 63u, s));
     A.keys = keys[1].as<unsigned long long>(); A.order = order[1].as<uint32_t>();
+    hipLaunchKernelGGL(k_lbvh_unit_sizes, grid, block, 0, s, A);
+    uint32_t n_placed = 0;
+    if (int rc = prefix_sum(A.tsize, A.toff, nu, n_placed)) return rc;
+    if (n_placed != n) return ctx->fail(RT_ERR_HIP, "BVH build: %u of %u triangles placed", n_placed, n);
     LbvhOut O{};
     O.node_base = node_base; O.rec_base = rec_base; O.tri_base = tri_base;
     HIP_TRY(ctx, out.tris->reserve((size_t)n * 48));
@@ -659,19 +687,7 @@ static int build_bvh_gpu(rt_ctx *ctx, const rt_mesh &m, uint32_t node_base, uint
         hipLaunchKernelGGL(k_lbvh_hierarchy, grid, block, 0, s, A);
         hipLaunchKernelGGL(k_lbvh_fit, grid, block, 0, s, A);
         hipLaunchKernelGGL(k_lbvh_mark_inner, grid, block, 0, s, A);
-        const auto scan = [&](DeviceBuf &flags, DeviceBuf &ranks, uint32_t &total) -> int {
-            size_t bytes = 0;
-            HIP_TRY(ctx, rocprim::exclusive_scan(nullptr, bytes, flags.as<uint32_t>(), ranks.as<uint32_t>(), 0u, (size_t)(n - 1), rocprim::plus<uint32_t>(), s));
-            HIP_TRY(ctx, tmp.reserve(std::max<size_t>(1, bytes)));
-            HIP_TRY(ctx, rocprim::exclusive_scan(tmp.p, bytes, flags.as<uint32_t>(), ranks.as<uint32_t>(), 0u, (size_t)(n - 1), rocprim::plus<uint32_t>(), s));
-            uint32_t last[2] = {0, 0};
-            HIP_TRY(ctx, hipMemcpyAsync(&last[0], flags.as<uint32_t>() + (n - 2), 4, hipMemcpyDeviceToHost, s));
-            HIP_TRY(ctx, hipMemcpyAsync(&last[1], ranks.as<uint32_t>() + (n - 2), 4, hipMemcpyDeviceToHost, s));
-            HIP_TRY(ctx, hipStreamSynchronize(s));
-            total = last[0] + last[1];
-            return RT_OK;
-        };
-        if (int rc = scan(inner, inner_rank, T)) return rc;
+        if (int rc = prefix_sum(inner.as<uint32_t>(), inner_rank.as<uint32_t>(), nu - 1, T)) return rc;
         hipLaunchKernelGGL(k_lbvh_depth, grid, block, 0, s, A, inner.as<uint32_t>());
         HIP_TRY(ctx, hipMemcpyAsync(&deepest, maxd.p, 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(ctx, hipStreamSynchronize(s));

@@ -57,6 +57,51 @@ def sah_tree(v, f, max_leaf):
     return np.stack(nodes), np.array(elements, np.uint32)
 
 
+def median_tree(v, f, pair):
+    """Spatial-median splits along the longest axis of the centroids' bounds (what a hierarchy over sorted keys amounts
+    to), over single triangles (pair False: two per leaf at most) or over pairs of consecutive faces that share an edge
+    (pair True: a pair is a leaf)."""
+    tv = v[f]
+    lo, hi = tv.min(1), tv.max(1)
+    if pair:
+        n2 = len(f) // 2
+        shared = np.array([len(set(f[2 * i]) & set(f[2 * i + 1])) == 2 for i in range(n2)])
+        assert shared.all() and len(f) % 2 == 0, "the experiment wants a mesh of quads cut in two"
+        ulo, uhi = np.minimum(lo[0::2], lo[1::2]), np.maximum(hi[0::2], hi[1::2])
+        faces_of = lambda u: [2 * u, 2 * u + 1]
+    else:
+        ulo, uhi = lo, hi
+        faces_of = lambda u: [u]
+    cen = 0.5 * (ulo + uhi)
+    nodes = [np.zeros(7, np.uint32), None]
+    elements = []
+    todo = [(1, np.arange(len(ulo)))]
+    max_units = 1 if pair else 2
+
+    def record(l, h, data):
+        w = np.zeros(7, np.uint32)
+        w[:3] = l.astype(np.float32).view(np.uint32); w[3:6] = h.astype(np.float32).view(np.uint32); w[6] = data
+        return w
+
+    while todo:
+        node, idx = todo.pop()
+        l, h = ulo[idx].min(0), uhi[idx].max(0)
+        if len(idx) <= max_units:
+            faces = [x for u in idx.tolist() for x in faces_of(u)]
+            nodes[node] = record(l, h, 0x80000000 | ((len(faces) - 1) << 28) | len(elements))
+            elements.extend(faces)
+            continue
+        c = cen[idx]
+        a = int(np.argmax(c.max(0) - c.min(0)))
+        o = idx[np.argsort(c[:, a], kind="stable")]
+        cut = len(o) // 2
+        k = len(nodes)
+        nodes.extend([None, None])
+        nodes[node] = record(l, h, k)
+        todo.append((k, o[:cut])); todo.append((k + 1, o[cut:]))
+    return np.stack(nodes), np.array(elements, np.uint32)
+
+
 def frames(hs, w, h, spp, env):
     for k, val in env.items():
         os.environ[k] = val
@@ -86,6 +131,13 @@ def main():
     print("the library's own tree (built on the GPU)            %8.2f ms/frame, ray launches %8.2f ms" % frames(hs, w, h, spp, {}))
     print("the reference's mean-split tree, collapsed            %8.2f ms/frame, ray launches %8.2f ms" % frames(hs, w, h, spp, {"RT_WIDE_GPU_BVH": "0"}))
     m = hs.desc.meshes[0]
+    for pair in (False, True):
+        nodes, elements = median_tree(np.asarray(mesh["v"], np.float64), np.asarray(mesh["f"], np.int64), pair)
+        nodes = np.ascontiguousarray(nodes, np.uint32); elements = np.ascontiguousarray(elements, np.uint32)
+        m.bvh_nodes = abi.C.cast(nodes.ctypes.data, abi.C.POINTER(abi.BvhNode)); m.n_bvh_nodes = len(nodes)
+        m.bvh_elements = elements.ctypes.data_as(abi.u32p); m.bvh_depth = abi.bvh_depth(nodes)
+        print(f"median splits over {'pairs of triangles that share an edge' if pair else 'triangles, two per leaf'}, collapsed"
+              "  %8.2f ms/frame, ray launches %8.2f ms" % frames(hs, w, h, spp, {"RT_WIDE_GPU_BVH": "0"}), flush=True)
     for max_leaf in (4, 2):
         t0 = time.time()
         nodes, elements = sah_tree(np.asarray(mesh["v"], np.float64), np.asarray(mesh["f"], np.int64), max_leaf)
