@@ -370,6 +370,7 @@ static int render_wavefront(rt_ctx *ctx, const DFrame &F, const int32_t *act, ui
     mix(&F, sizeof F); mix(&items, sizeof items); mix(&k0, sizeof k0); mix(&nk, sizeof nk); mix(&act, sizeof act);
     mix(&ctx->scene_generation, sizeof ctx->scene_generation); mix(&ctx->finish_below, sizeof ctx->finish_below);
     mix(ctx->active_key, sizeof ctx->active_key); // which pixels: image size, tiles, shard
+    mix(&ctx->counting, sizeof ctx->counting);     // (the counting variant walks the reference's binary tree: a hit an ulp away can end a path elsewhere)
     const rt_ctx::WfProfile *known = nullptr;
     if (ctx->wf_replay) for (const auto &pr : ctx->wf_profiles) if (pr.key == key) known = &pr;
     std::vector<WfCounts> seen; // cnt[0..] as the host learns them (or takes them from the profile)
