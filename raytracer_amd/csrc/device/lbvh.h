@@ -23,7 +23,7 @@ constexpr uint32_t kLbvhMaxLeafTris = 4, kLbvhWideLeafTris = 2;
 
 // What the tree is built over is not single triangles but UNITS: two consecutive faces of the mesh that share an edge -
 // the two halves of a quad, which is how most meshes of triangles come about - are one unit, any other face is a unit
-// by itself.  A unit is never split, so the two halves of a quad land in one leaf, whose box is the quad's; a hierarchy
+// by itself (k_lbvh_units below).  A unit is never split, so the two halves of a quad land in one leaf, whose box is the quad's; a hierarchy
 // over the triangles' own centres pairs a triangle with whatever neighbour its key happens to be next to.  Measured with
 // trees built offline (tests/bench_sah_tree.py, ray launches of the 1M-triangle frame): median splits over triangles
 // 49.8 ms, over such pairs 45.0 ms.
@@ -78,26 +78,40 @@ RT_DEV void unit_box(const LbvhArrays &A, uint32_t unit, float *b)
     }
 }
 
-// the units: faces 2i and 2i + 1 together if they have two corners in common, else each by itself
+// The units: a face and the next one together if they have two corners in common.  Where several consecutive faces
+// each share an edge with the next (a strip, a row of quads), pairs are made from the start of that run: first and
+// second, third and fourth, and so on.
+//   k_lbvh_run_marks   mark[i] = i where a run starts (face i has no edge in common with face i - 1), else 0; an
+//                      inclusive maximum scan turns the marks into every face's run start
+//   k_lbvh_unit_heads  head[i] = 1 unless face i is the second of a pair; an exclusive prefix sum numbers the units
+//   k_lbvh_units       unit[number] = i | (first of a pair) << 31
 RT_DEV bool lbvh_faces_pair(const uint32_t *f, uint32_t a, uint32_t b)
 {
     int common = 0;
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) common += f[a * 3 + i] == f[b * 3 + j] ? 1 : 0;
     return common >= 2;
 }
-__global__ __launch_bounds__(kBlock) void k_lbvh_unit_counts(const uint32_t *__restrict__ f, uint32_t n_faces, uint32_t *__restrict__ count)
+__global__ __launch_bounds__(kBlock) void k_lbvh_run_marks(const uint32_t *__restrict__ f, uint32_t n_faces, uint32_t *__restrict__ mark)
 {
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; 2 * i < n_faces; i += gridDim.x * kBlock)
-        count[i] = (2 * i + 1 < n_faces && !lbvh_faces_pair(f, 2 * i, 2 * i + 1)) ? 2u : 1u;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_faces; i += gridDim.x * kBlock)
+        mark[i] = (i > 0 && !lbvh_faces_pair(f, i - 1, i)) ? i : 0u;
 }
-__global__ __launch_bounds__(kBlock) void k_lbvh_units(const uint32_t *__restrict__ f, uint32_t n_faces, const uint32_t *__restrict__ count,
-                                                       const uint32_t *__restrict__ first, uint32_t *__restrict__ unit)
+// is face i the first of a pair?  (it continues its run, and stands at an even place in it)
+RT_DEV bool lbvh_pair_starts(const uint32_t *f, uint32_t n_faces, const uint32_t *run_start, uint32_t i)
 {
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; 2 * i < n_faces; i += gridDim.x * kBlock) {
-        const uint32_t u = first[i];
-        if (count[i] == 2) { unit[u] = 2 * i; unit[u + 1] = 2 * i + 1; }
-        else unit[u] = 2 * i | (2 * i + 1 < n_faces ? 0x80000000u : 0u);
-    }
+    return i + 1 < n_faces && run_start[i + 1] == run_start[i] && ((i - run_start[i]) & 1u) == 0;
+}
+__global__ __launch_bounds__(kBlock) void k_lbvh_unit_heads(const uint32_t *__restrict__ f, uint32_t n_faces, const uint32_t *__restrict__ run_start,
+                                                            uint32_t *__restrict__ head)
+{
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_faces; i += gridDim.x * kBlock)
+        head[i] = (i > 0 && lbvh_pair_starts(f, n_faces, run_start, i - 1)) ? 0u : 1u;
+}
+__global__ __launch_bounds__(kBlock) void k_lbvh_units(const uint32_t *__restrict__ f, uint32_t n_faces, const uint32_t *__restrict__ run_start,
+                                                       const uint32_t *__restrict__ head, const uint32_t *__restrict__ number, uint32_t *__restrict__ unit)
+{
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_faces; i += gridDim.x * kBlock)
+        if (head[i]) unit[number[i]] = i | (lbvh_pair_starts(f, n_faces, run_start, i) ? 0x80000000u : 0u);
 }
 
 // Sort key of every unit: the cell of its box centre inside the mesh's bounds (21 bits per axis), the bits of the three

@@ -617,7 +617,7 @@ static int build_bvh_gpu(rt_ctx *ctx, const rt_mesh &m, uint32_t node_base, uint
     }
     for (int a = 0; a < 3; ++a) { out.bounds[a] = lo[a]; out.bounds[3 + a] = hi[a]; }
     DeviceBuf d_v, d_f, keys[2], order[2], child, parent, leaf_parent, range, ibox, lbox, arrived, inner, inner_rank, front, level_count, maxd, tmp;
-    DeviceBuf unit, unit_count, unit_first, tsize, toff;
+    DeviceBuf unit, unit_count, unit_first, run_start, tsize, toff;
     HIP_TRY(ctx, d_v.reserve((size_t)m.nv * 12)); HIP_TRY(ctx, d_f.reserve((size_t)n * 12));
     HIP_TRY(ctx, hipMemcpyAsync(d_v.p, m.v, (size_t)m.nv * 12, hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemcpyAsync(d_f.p, m.f, (size_t)n * 12, hipMemcpyHostToDevice, s));
@@ -660,12 +660,18 @@ static int build_bvh_gpu(rt_ctx *ctx, const rt_mesh &m, uint32_t node_base, uint
         return RT_OK;
     };
     // the units the tree is built over: pairs of consecutive faces that share an edge, and the faces that are left (device/lbvh.h)
-    const uint32_t slots = (n + 1) / 2;
     uint32_t nu = 0;
-    HIP_TRY(ctx, unit_count.reserve((size_t)slots * 4)); HIP_TRY(ctx, unit_first.reserve((size_t)slots * 4));
-    hipLaunchKernelGGL(k_lbvh_unit_counts, grid, block, 0, s, A.f, n, unit_count.as<uint32_t>());
-    if (int rc = prefix_sum(unit_count.as<uint32_t>(), unit_first.as<uint32_t>(), slots, nu)) return rc;
-    hipLaunchKernelGGL(k_lbvh_units, grid, block, 0, s, A.f, n, unit_count.as<uint32_t>(), unit_first.as<uint32_t>(), A.unit);
+    HIP_TRY(ctx, unit_count.reserve((size_t)n * 4)); HIP_TRY(ctx, unit_first.reserve((size_t)n * 4)); HIP_TRY(ctx, run_start.reserve((size_t)n * 4));
+    hipLaunchKernelGGL(k_lbvh_run_marks, grid, block, 0, s, A.f, n, unit_count.as<uint32_t>());
+    {
+        size_t bytes = 0;
+        HIP_TRY(ctx, rocprim::inclusive_scan(nullptr, bytes, unit_count.as<uint32_t>(), run_start.as<uint32_t>(), (size_t)n, rocprim::maximum<uint32_t>(), s));
+        HIP_TRY(ctx, tmp.reserve(std::max<size_t>(1, bytes)));
+        HIP_TRY(ctx, rocprim::inclusive_scan(tmp.p, bytes, unit_count.as<uint32_t>(), run_start.as<uint32_t>(), (size_t)n, rocprim::maximum<uint32_t>(), s));
+    }
+    hipLaunchKernelGGL(k_lbvh_unit_heads, grid, block, 0, s, A.f, n, run_start.as<uint32_t>(), unit_count.as<uint32_t>());
+    if (int rc = prefix_sum(unit_count.as<uint32_t>(), unit_first.as<uint32_t>(), n, nu)) return rc;
+    hipLaunchKernelGGL(k_lbvh_units, grid, block, 0, s, A.f, n, run_start.as<uint32_t>(), unit_count.as<uint32_t>(), unit_first.as<uint32_t>(), A.unit);
     A.n = nu;
     hipLaunchKernelGGL(k_lbvh_keys, grid, block, 0, s, A, lo[0], lo[1], lo[2], scale(0), scale(1), scale(2), axes);
     size_t tmp_bytes = 0;

@@ -174,3 +174,44 @@ def test_gpu_built_tree_is_as_good_as_the_references(nx, ny, w, h):
         assert counts[True][1] <= 1.05 * counts[False][1], f"triangle tests {counts[True][1]} against {counts[False][1]}"
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("order", ["a lone triangle first", "shuffled faces", "every quad's halves far apart in the file"])
+def test_gpu_bvh_whatever_the_order_of_the_faces(order):
+    """The GPU builder pairs consecutive faces that share an edge (the halves of a quad) into units that share a leaf.
+    Whether and how faces pair must not matter to any answer: the small mesh with its faces rearranged - a lone triangle
+    in front (every later quad starts at an odd place), shuffled (hardly a pair left), the halves of every quad far
+    apart (no pairs at all) - must give the rays' answers of the reference's own tree over the same faces, bit for bit,
+    through the binary walk and through the four-wide one (ids equal, t within an ulp in all but two rays)."""
+    g = O.load_golden("scene_mesh")
+    mesh = scenes.heightfield(32, 16)
+    f = np.asarray(mesh["f"], np.uint32)
+    rng = np.random.default_rng(5)
+    if order == "a lone triangle first":
+        f = np.concatenate([f[-1:], f[:-1]])
+    elif order == "shuffled faces":
+        f = f[rng.permutation(len(f))]
+    else:
+        f = np.concatenate([f[0::2], f[1::2]])
+    rays = O.load_golden("kat_trace_mesh")["kat_rays"]
+    answers = {}
+    for gpu_bvh, wide in ((False, "0"), (True, "0"), (True, "1")):
+        hs = lib.HostScene.from_string(bytes(g["xml"]).decode())
+        hs.set_gpu_bvh(gpu_bvh)
+        hs.set_mesh("mesh_small.obj", mesh["v"], mesh["vt"], f)
+        mp = pytest.MonkeyPatch()
+        mp.setenv("RT_QUERY_WIDE", wide)
+        ctx = lib.Context(0)
+        mp.undo()
+        try:
+            ctx.upload(hs.desc)
+            answers[(gpu_bvh, wide)] = ctx.trace_brief(rays)
+        finally:
+            ctx.close()
+    ref, binary, four = answers[(False, "0")], answers[(True, "0")], answers[(True, "1")]
+    assert (ref["node"] >= 0).sum() > 100
+    assert np.array_equal(binary["node"], ref["node"]) and np.array_equal(bits(binary["t"]), bits(ref["t"]))
+    assert np.array_equal(four["node"], ref["node"])
+    d = np.abs(bits(four["t"]).astype(np.int64) - bits(ref["t"]).astype(np.int64))
+    assert d.max() <= 1 and (d != 0).sum() <= 2
