@@ -262,3 +262,30 @@ def test_wide_bvh_records_contain_their_childrens_boxes():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and r.stdout.startswith("ok "), r.stdout + r.stderr
     assert int(r.stdout.split()[1]) > 400_000
+
+
+def test_hot_kernels_keep_their_state_in_registers(tmp_path):
+    """The frames' kernels are built for four waves per SIMD: at most 128 registers and nothing in scratch.  A change
+    that makes the compiler put part of the ray walker's state into private memory costs a quarter of the frame and
+    shows in no result, only in the code object's metadata - which is read here (llvm-objdump --offloading,
+    llvm-readelf --notes)."""
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not os.path.exists(os.path.join(llvm, "llvm-objdump")):
+        pytest.skip("no ROCm LLVM tools here")
+    import shutil
+    so = shutil.copy(os.path.join(ROOT, "raytracer_amd", "librt_mi355x.so"), tmp_path / "lib.so")
+    subprocess.run([os.path.join(llvm, "llvm-objdump"), "--offloading", str(so)], check=True, capture_output=True, cwd=tmp_path)
+    obj = [p for p in os.listdir(tmp_path) if "gfx950" in p]
+    assert len(obj) == 1, os.listdir(tmp_path)
+    notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", str(tmp_path / obj[0])], check=True, capture_output=True, text=True).stdout
+    kernels = {}
+    for block in notes.split("  - .agpr_count:")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", block).group(1)
+        kernels[name] = {k: int(re.search(rf"\.{k}:\s+(\d+)", block).group(1)) for k in ("private_segment_fixed_size", "vgpr_count", "vgpr_spill_count")}
+    # the ray-list kernel for scenes whose objects are not nested (one local ray; the instantiations for deeper
+    # hierarchies keep up to five and spill a register or two), and the shading kernel
+    hot = [n for n in kernels if ("6k_raysILb0ELi1E" in n or "6k_raysILb0ELi0E" in n or "10k_wf_shadeILb" in n)]
+    assert len(hot) >= 8, sorted(kernels)[:5]
+    for n in hot:
+        k = kernels[n]
+        assert k["vgpr_count"] <= 128 and k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, (n, k)
