@@ -102,6 +102,63 @@ def median_tree(v, f, pair):
     return np.stack(nodes), np.array(elements, np.uint32)
 
 
+def curve_order(cen):
+    """Units along the builder's space-filling curve: 21 bits per axis, every key bit from the axis whose cells are
+    still the widest (device/lbvh.h: lbvh_axis_order)."""
+    lo, hi = cen.min(0), cen.max(0)
+    size = (hi - lo).astype(np.float64).copy()
+    cells = np.minimum(((cen - lo) / np.maximum(hi - lo, 1e-30) * 2097151.0).astype(np.uint64), 2097151)
+    left = [21, 21, 21]
+    key = np.zeros(len(cen), np.uint64)
+    for _ in range(63):
+        a = max((k for k in range(3) if left[k] > 0), key=lambda k: size[k])
+        size[a] *= 0.5; left[a] -= 1
+        key = (key << np.uint64(1)) | ((cells[:, a] >> np.uint64(left[a])) & np.uint64(1))
+    return np.argsort(key, kind="stable")
+
+
+def curve_sah_tree(v, f):
+    """Pairs of triangles in curve order; every node splits its stretch of the curve where the surface-area cost is
+    smallest (one sweep along the order, not along the three axes): what a builder could do level by level with
+    segmented scans over the sorted units."""
+    tv = v[f]
+    lo, hi = tv.min(1), tv.max(1)
+    ulo, uhi = np.minimum(lo[0::2], lo[1::2]), np.maximum(hi[0::2], hi[1::2])
+    o = curve_order(0.5 * (ulo + uhi))
+    ulo, uhi = ulo[o], uhi[o]
+    nodes = [np.zeros(7, np.uint32), None]
+    elements = []
+    todo = [(1, 0, len(o))]
+
+    def area(l, h):
+        d = h - l
+        return d[..., 0] * d[..., 1] + d[..., 1] * d[..., 2] + d[..., 2] * d[..., 0]
+
+    def record(l, h, data):
+        w = np.zeros(7, np.uint32)
+        w[:3] = l.astype(np.float32).view(np.uint32); w[3:6] = h.astype(np.float32).view(np.uint32); w[6] = data
+        return w
+
+    while todo:
+        node, a, b = todo.pop()
+        l, h = ulo[a:b].min(0), uhi[a:b].max(0)
+        n = b - a
+        if n == 1:
+            u = int(o[a])
+            nodes[node] = record(l, h, 0x80000000 | (1 << 28) | len(elements))
+            elements.extend([2 * u, 2 * u + 1])
+            continue
+        ll, lh = np.minimum.accumulate(ulo[a:b], 0), np.maximum.accumulate(uhi[a:b], 0)
+        rl, rh = np.minimum.accumulate(ulo[a:b][::-1], 0)[::-1], np.maximum.accumulate(uhi[a:b][::-1], 0)[::-1]
+        k = np.arange(1, n)
+        cut = a + 1 + int(np.argmin(area(ll[:-1], lh[:-1]) * k + area(rl[1:], rh[1:]) * (n - k)))
+        c = len(nodes)
+        nodes.extend([None, None])
+        nodes[node] = record(l, h, c)
+        todo.append((c, a, cut)); todo.append((c + 1, cut, b))
+    return np.stack(nodes), np.array(elements, np.uint32)
+
+
 def frames(hs, w, h, spp, env):
     for k, val in env.items():
         os.environ[k] = val
@@ -138,6 +195,12 @@ def main():
         m.bvh_elements = elements.ctypes.data_as(abi.u32p); m.bvh_depth = abi.bvh_depth(nodes)
         print(f"median splits over {'pairs of triangles that share an edge' if pair else 'triangles, two per leaf'}, collapsed"
               "  %8.2f ms/frame, ray launches %8.2f ms" % frames(hs, w, h, spp, {"RT_WIDE_GPU_BVH": "0"}), flush=True)
+    nodes, elements = curve_sah_tree(np.asarray(mesh["v"], np.float64), np.asarray(mesh["f"], np.int64))
+    nodes = np.ascontiguousarray(nodes, np.uint32); elements = np.ascontiguousarray(elements, np.uint32)
+    m.bvh_nodes = abi.C.cast(nodes.ctypes.data, abi.C.POINTER(abi.BvhNode)); m.n_bvh_nodes = len(nodes)
+    m.bvh_elements = elements.ctypes.data_as(abi.u32p); m.bvh_depth = abi.bvh_depth(nodes)
+    print(f"pairs in curve order, every node split where the cost along the curve is smallest (depth {m.bvh_depth}), collapsed"
+          "  %8.2f ms/frame, ray launches %8.2f ms" % frames(hs, w, h, spp, {"RT_WIDE_GPU_BVH": "0"}), flush=True)
     for max_leaf in (4, 2):
         t0 = time.time()
         nodes, elements = sah_tree(np.asarray(mesh["v"], np.float64), np.asarray(mesh["f"], np.int64), max_leaf)
